@@ -1,0 +1,189 @@
+"""Seeded synthetic weights and the flat weight-blob format the HIP library loads.
+
+There is no checkpoint in /root/reference ("checkpoint / resume: absent"),
+so all measurements use seeded random weights (seed 1234, T5-style init scales,
+untied lm_head).  Matrices are stored as [out_features][in_features] bf16 (the layout both
+the MFMA B-fragment loads and the oracle's `x @ W.T` want); norm gains, biases and the
+relative-position tables are fp32.
+
+Blob layout (little endian):
+    char     magic[8] = "YMT3BLOB"
+    uint32   version  = 1
+    uint32   n_tensors
+    entry[n] { char name[48]; uint32 dtype; uint32 ndim; uint32 shape[4];
+               uint64 offset; uint64 nbytes }               (88 bytes each)
+    data     every tensor starts on a 256-byte boundary, offsets from blob start
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .config import YMT3Config, ENC_PERCEIVER_TF, FFN_MOE
+
+MAGIC = b"YMT3BLOB"
+DT_F32, DT_BF16, DT_I32 = 0, 1, 2
+_ENTRY = struct.Struct("<48sII4IQQ")
+
+
+def f32_to_bf16_bits(x: torch.Tensor) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16, returned as uint16 bit patterns."""
+    return x.detach().to(torch.float32).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def bf16_bits_to_f32(bits: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy((bits.astype(np.uint32) << 16).view(np.float32).copy())
+
+
+def make_weights(cfg: YMT3Config, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """fp32 tensors that are exactly representable in bf16 where the blob stores bf16.
+
+    Init scales follow the T5 scheme (TP: transformers/models/t5/modeling_t5.py `_init_weights`):
+    q ~ (d_model*d_kv)^-1/2, k/v/wi ~ d_model^-1/2, o ~ inner^-1/2, wo ~ d_ff^-1/2.  The lm_head is
+    untied (SURVEY section 7 "Hard parts": a tied random head collapses greedy decode to one id).
+    """
+    g = torch.Generator().manual_seed(seed)
+    d, dff, inner, V = cfg.d_model, cfg.d_ff, cfg.inner, cfg.vocab
+
+    def mat(out_f, in_f, std):
+        w = torch.randn(out_f, in_f, generator=g) * std
+        return w.to(torch.bfloat16).to(torch.float32)
+
+    def gain(n):
+        return (1.0 + 0.1 * torch.randn(n, generator=g)).to(torch.float32)
+
+    W: Dict[str, torch.Tensor] = {}
+    W["in_proj.w"] = mat(d, cfg.n_mels, cfg.n_mels ** -0.5 * 0.25)
+    W["in_proj.b"] = (0.02 * torch.randn(d, generator=g)).float()
+
+    def attn_block(prefix):
+        q = mat(inner, d, (d * cfg.d_kv) ** -0.5 * 4.0)
+        k = mat(inner, d, d ** -0.5)
+        v = mat(inner, d, d ** -0.5)
+        return q, k, v, mat(d, inner, inner ** -0.5)
+
+    for l in range(cfg.n_enc_layers):
+        p = f"enc.{l}."
+        q, k, v, o = attn_block(p)
+        W[p + "ln1"] = gain(d)
+        W[p + "wqkv"] = torch.cat([q, k, v], 0)
+        W[p + "wo"] = o
+        W[p + "ln2"] = gain(d)
+        W[p + "wi"] = mat(dff, d, d ** -0.5)
+        W[p + "wo2"] = mat(d, dff, dff ** -0.5)
+    W["enc.relbias"] = (torch.randn(cfg.rel_buckets, cfg.n_heads, generator=g) * 0.5).float()
+    W["enc.ln_f"] = gain(d)
+
+    if cfg.encoder_type == ENC_PERCEIVER_TF:
+        _perceiver_weights(cfg, W, g, mat, gain)
+
+    # std 6: keeps the residual stream token-dominated so greedy streams stay token- AND context-
+    # dependent instead of collapsing to one id (observed with std 1: 1-4 distinct ids per 96 steps)
+    W["dec.embed"] = mat(V, d, 6.0)
+    if cfg.n_channels > 1:
+        W["dec.chan_embed"] = mat(cfg.n_channels, d, 3.0)
+    for l in range(cfg.n_dec_layers):
+        p = f"dec.{l}."
+        q, k, v, o = attn_block(p)
+        W[p + "ln1"] = gain(d)
+        W[p + "wqkv"] = torch.cat([q, k, v], 0)
+        W[p + "wo"] = o
+        q, k, v, o = attn_block(p)
+        W[p + "ln2"] = gain(d)
+        W[p + "wq_c"] = q
+        W[p + "wkv_c"] = torch.cat([k, v], 0)
+        W[p + "wo_c"] = o
+        W[p + "ln3"] = gain(d)
+        if cfg.dec_ffn == FFN_MOE:
+            W[p + "router"] = mat(cfg.n_experts, d, d ** -0.5)
+            W[p + "wi"] = mat(cfg.n_experts * dff, d, d ** -0.5)
+            W[p + "wo2"] = mat(cfg.n_experts * d, dff, dff ** -0.5)
+        else:
+            W[p + "wi"] = mat(dff, d, d ** -0.5)
+            W[p + "wo2"] = mat(d, dff, dff ** -0.5)
+    W["dec.relbias"] = (torch.randn(cfg.rel_buckets, cfg.n_heads, generator=g) * 0.5).float()
+    W["dec.ln_f"] = gain(d)
+    W["dec.lm_head"] = mat(V, d, d ** -0.5)
+    return W
+
+
+def _perceiver_weights(cfg, W, g, mat, gain):
+    """Perceiver-TF encoder parameters (build-defined spec, see DESIGN.md section 'Perceiver-TF')."""
+    d, dff, inner = cfg.d_model, cfg.d_ff, cfg.inner
+    W["ptf.latents"] = mat(cfg.n_latents, d, 1.0)
+    for l in range(cfg.n_enc_layers):
+        p = f"ptf.{l}."
+        for name in ("sca", "lat", "tmp"):     # spectral cross-attn, latent self-attn, temporal self-attn
+            W[p + name + ".ln"] = gain(d)
+            W[p + name + ".wq"] = mat(inner, d, (d * cfg.d_kv) ** -0.5 * 4.0)
+            W[p + name + ".wkv"] = torch.cat([mat(inner, d, d ** -0.5), mat(inner, d, d ** -0.5)], 0)
+            W[p + name + ".wo"] = mat(d, inner, inner ** -0.5)
+        W[p + "sca.ln_kv"] = gain(d)
+        W[p + "ln_ff"] = gain(d)
+        W[p + "wi"] = mat(dff, d, d ** -0.5)
+        W[p + "wo2"] = mat(d, dff, dff ** -0.5)
+
+
+_BF16_SUFFIX = ("w", "wqkv", "wo", "wi", "wo2", "wq_c", "wkv_c", "wo_c", "embed", "chan_embed",
+                "lm_head", "router", "latents", "wq", "wkv")
+
+
+def is_bf16_tensor(name: str) -> bool:
+    return name.rsplit(".", 1)[-1] in _BF16_SUFFIX
+
+
+def pack_blob(W: Dict[str, torch.Tensor]) -> bytes:
+    names = list(W.keys())
+    header_len = 8 + 4 + 4 + _ENTRY.size * len(names)
+    off = (header_len + 255) // 256 * 256
+    entries, chunks = [], []
+    for n in names:
+        t = W[n]
+        if is_bf16_tensor(n):
+            raw = f32_to_bf16_bits(t).tobytes()
+            dt = DT_BF16
+        elif t.dtype in (torch.int32,):
+            raw = t.numpy().astype(np.int32).tobytes()
+            dt = DT_I32
+        else:
+            raw = t.detach().float().numpy().tobytes()
+            dt = DT_F32
+        shape = list(t.shape) + [1] * (4 - t.dim())
+        entries.append(_ENTRY.pack(n.encode()[:47], dt, t.dim(), *shape, off, len(raw)))
+        chunks.append((off, raw))
+        off = (off + len(raw) + 255) // 256 * 256
+    buf = bytearray(off)
+    buf[0:8] = MAGIC
+    struct.pack_into("<II", buf, 8, 1, len(names))
+    pos = 16
+    for e in entries:
+        buf[pos:pos + _ENTRY.size] = e
+        pos += _ENTRY.size
+    for o, raw in chunks:
+        buf[o:o + len(raw)] = raw
+    return bytes(buf)
+
+
+def unpack_blob(blob: bytes) -> Dict[str, torch.Tensor]:
+    assert blob[:8] == MAGIC, "not a YMT3 weight blob"
+    ver, n = struct.unpack_from("<II", blob, 8)
+    assert ver == 1
+    out = {}
+    pos = 16
+    for _ in range(n):
+        name, dt, ndim, s0, s1, s2, s3, off, nbytes = _ENTRY.unpack_from(blob, pos)
+        pos += _ENTRY.size
+        name = name.rstrip(b"\0").decode()
+        shape = [s0, s1, s2, s3][:ndim]
+        raw = blob[off:off + nbytes]
+        if dt == DT_BF16:
+            t = bf16_bits_to_f32(np.frombuffer(raw, dtype=np.uint16)).reshape(shape)
+        elif dt == DT_I32:
+            t = torch.from_numpy(np.frombuffer(raw, dtype=np.int32).copy()).reshape(shape)
+        else:
+            t = torch.from_numpy(np.frombuffer(raw, dtype=np.float32).copy()).reshape(shape)
+        out[name] = t
+    return out
