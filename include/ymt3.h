@@ -1,0 +1,90 @@
+/*
+ * ymt3.h -- C ABI of the MI355X (gfx950) audio -> MIDI-token hot path.
+ *
+ * Drop-in boundary.  The reference checkout holds no source
+ * (/root/reference = README.md:1-13 + LICENSE), so no reference file:line can be cited for
+ * the interface each entry point replaces; the names `transcribe()` / `TaskManager` /
+ * `inference_file()` come from BASELINE.json `north_star` and SURVEY.md section 9 (unverified
+ * recollection of upstream `model/ymt3.py::inference_file(bsz, audio_segments)`).  The entry
+ * points below are what a ctypes / cffi / pybind stub on that Python path would bind:
+ *
+ *   inference_file(bsz, audio_segments)  ->  ymt3_transcribe_segments()
+ *   spectrogram module forward           ->  ymt3_logmel()
+ *   encoder forward                      ->  ymt3_encode()
+ *   decoder generate (greedy, KV cache)  ->  ymt3_decode_greedy()
+ *
+ * Conventions
+ *   - every pointer named *_dev is DEVICE memory on the handle's GPU, owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all calls are
+ *     asynchronous with respect to the host and never synchronise the device;
+ *   - the library owns weights, KV caches and scratch inside the handle; nothing is
+ *     allocated after ymt3_create();
+ *   - return value: 0 = ok, non-zero = error; the message is in ymt3_last_error()
+ *     (thread local).  No exception ever crosses this boundary;
+ *   - one handle per device per host thread.  No internal host threads.
+ */
+#ifndef YMT3_H
+#define YMT3_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YMT3_ABI_VERSION 1
+
+enum { YMT3_OK = 0, YMT3_ERR_ARG = 1, YMT3_ERR_BLOB = 2, YMT3_ERR_HIP = 3, YMT3_ERR_UNSUPPORTED = 4 };
+enum { YMT3_ENC_T5 = 0, YMT3_ENC_PERCEIVER_TF = 1 };
+enum { YMT3_FFN_DENSE = 0, YMT3_FFN_MOE = 1 };
+
+/* Field order mirrors yourmt3_amd/config.py::CConfig. */
+typedef struct ymt3_config {
+    int32_t sample_rate, segment_samples, n_fft, hop, n_mels;
+    float   f_min, f_max, log_floor;
+    int32_t d_model, d_ff, n_heads, d_kv, n_enc_layers, n_dec_layers;
+    int32_t vocab, rel_buckets, rel_max_distance;
+    float   ln_eps;
+    int32_t max_decode_len, n_channels, eos_id, pad_id;
+    int32_t encoder_type, n_latents;
+    int32_t dec_ffn, n_experts, moe_top_k;
+    int32_t max_batch;              /* segments per call the workspace is sized for */
+} ymt3_config;
+
+typedef struct ymt3_ctx* ymt3_handle;
+
+int         ymt3_abi_version(void);
+const char* ymt3_last_error(void);
+
+/* Parse the weight blob (format: yourmt3_amd/weights.py), upload it to `device`, derive the
+ * window / twiddle / mel / relative-position tables, allocate caches and scratch. */
+int  ymt3_create(const ymt3_config* cfg, const void* blob_host, size_t blob_bytes, int device, ymt3_handle* out);
+void ymt3_destroy(ymt3_handle h);
+
+/* Bytes of device memory held by the handle (weights + caches + scratch). */
+size_t ymt3_device_bytes(ymt3_handle h);
+
+/* a1+a2: audio (B, segment_samples) f32 -> log-mel (B, n_frames, n_mels) f32. */
+int ymt3_logmel(ymt3_handle h, const float* audio_dev, int B, float* mel_dev, void* stream);
+
+/* a3+a4 (or a9): log-mel (B, n_frames, n_mels) f32 -> encoder output (B, n_frames, d_model) bf16. */
+int ymt3_encode(ymt3_handle h, const float* mel_dev, int B, void* enc_dev, void* stream);
+
+/* a6+a7+a8(+a10): encoder output bf16 -> greedy token ids (B, n_channels, n_steps) int32.
+ * forced_dev (may be NULL): (B, n_channels, n_steps) int32 teacher-forcing ids fed back instead of
+ * the argmax.  logits_dev (may be NULL): (B, n_channels, n_steps, vocab) f32 per-step logits. */
+int ymt3_decode_greedy(ymt3_handle h, const void* enc_dev, int B, int n_steps, int32_t* tokens_dev,
+                       const int32_t* forced_dev, float* logits_dev, void* stream);
+
+/* The whole hot path: audio (B, segment_samples) f32 -> token ids (B, n_channels, n_steps) int32. */
+int ymt3_transcribe_segments(ymt3_handle h, const float* audio_dev, int B, int n_steps,
+                             int32_t* tokens_dev, void* stream);
+
+/* Unit-test hooks: C = A(bf16 MxK) * W^T(bf16 NxK), f32 out; runs the encoder GEMM kernel. */
+int ymt3_test_gemm(ymt3_handle h, const void* a_dev, const void* w_dev, float* c_dev, int M, int N, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YMT3_H */

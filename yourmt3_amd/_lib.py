@@ -1,0 +1,60 @@
+"""ctypes binding of the C ABI in include/ymt3.h.  No fallback: if the HIP library is missing
+or fails to load, importing a model raises -- the product path never routes through a CPU restatement.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .config import CConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libymt3_hip.so")
+
+# every symbol include/ymt3.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "ymt3_abi_version", "ymt3_last_error", "ymt3_create", "ymt3_destroy", "ymt3_device_bytes",
+    "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm",
+]
+
+_lib = None
+
+
+class YMT3Error(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YMT3Error(
+            f"{LIB_PATH} not found: build it with `python -m yourmt3_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.ymt3_abi_version.restype = i32
+    lib.ymt3_last_error.restype = ctypes.c_char_p
+    lib.ymt3_create.argtypes = [ctypes.POINTER(CConfig), vp, sz, i32, ctypes.POINTER(vp)]
+    lib.ymt3_create.restype = i32
+    lib.ymt3_destroy.argtypes = [vp]
+    lib.ymt3_destroy.restype = None
+    lib.ymt3_device_bytes.argtypes = [vp]
+    lib.ymt3_device_bytes.restype = sz
+    lib.ymt3_logmel.argtypes = [vp, vp, i32, vp, vp]
+    lib.ymt3_encode.argtypes = [vp, vp, i32, vp, vp]
+    lib.ymt3_decode_greedy.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.ymt3_transcribe_segments.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.ymt3_test_gemm.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    for n in ("ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm"):
+        getattr(lib, n).restype = i32
+    if lib.ymt3_abi_version() != 1:
+        raise YMT3Error("libymt3_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise YMT3Error(f"ymt3 error {rc}: {load().ymt3_last_error().decode(errors='replace')}")

@@ -1,0 +1,147 @@
+// Encoder self-attention (a4/a5 of SURVEY.md section 8): softmax(Q K^T + rel_bias) V per (segment,
+// head), no 1/sqrt(d) scale (TP: transformers/models/t5/modeling_t5.py:196-197), bias added
+// before the softmax (:159-167), one bias table shared by all layers (:739-742).
+//
+// One workgroup = one (segment, head, 64-query tile); 4 waves x 16 queries.  K and V of the whole
+// segment (T <= 512 keys x 64) live in LDS.  Scores are computed TRANSPOSED, S^T = K Q^T, with
+// v_mfma_f32_16x16x32_bf16 so that each lane owns ONE query column and 4 consecutive keys per
+// accumulator: the softmax reductions are lane-local plus two shuffles, and the exponentials,
+// rounded to bf16, are already the B operand of the second product O^T = V^T P^T.  V^T fragments come
+// from the row-major LDS image through ds_read_b64_tr_b16 (hardware transpose), so nothing is
+// transposed in memory.  All T keys are resident, so there is no online rescale: max and sum are exact.
+//
+// Numerics contract: e = exp(s - max) rounded to bf16 for P.V, the normaliser sums the
+// unrounded fp32 e, output rounded to bf16.  Oracle: oracle/ymt3_oracle.py::attention(round_p=True).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int DKV = 64;
+constexpr int ROWB = 144;   // LDS row pitch in bytes (128 + 16 pad: spreads rows over the banks)
+
+template <int T>
+__global__ __launch_bounds__(256) void enc_attn_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_off,
+                                                       bf16_t* __restrict__ out, int H) {
+    constexpr int NT = T / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + T * ROWB;
+    float* sB = reinterpret_cast<float*>(smem + 2 * T * ROWB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int inner = H * DKV, ld = 3 * inner;
+    const bf16_t* base = qkv + (size_t)b * T * ld + h * DKV;
+
+    for (int idx = tid; idx < T * 8; idx += 256) {
+        const int row = idx >> 3, ch = idx & 7;
+        const bf16_t* src = base + (size_t)row * ld + ch * 8;
+        *reinterpret_cast<uint4*>(sK + row * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(src + inner);
+        *reinterpret_cast<uint4*>(sV + row * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(src + 2 * inner);
+    }
+    for (int i = tid; i < 2 * T - 1; i += 256) sB[i] = bias_off[(size_t)h * (2 * T - 1) + i];
+
+    const int g = lane >> 4, li = lane & 15;
+    const int q = qt * 64 + wave * 16 + li;             // this lane's query (position in segment)
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + (size_t)q * ld + ks * 32 + g * 8));
+    __syncthreads();
+
+    // S^T tiles: lane -> query q, keys kt*16 + 4g + r
+    f32x4 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 kf = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const uint4*>(sK + (kt * 16 + li) * ROWB + (ks * 4 + g) * 16));
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+        }
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            s[kt][r] += sB[key - q + T - 1];
+            mx = fmaxf(mx, s[kt][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __expf(s[kt][r] - mx);
+            s[kt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+
+    // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; k-step = key tiles (2kp, 2kp+1)
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+    for (int kp = 0; kp < NT / 2; ++kp) {
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf[r] = (__bf16)s[2 * kp][r];
+            pf[4 + r] = (__bf16)s[2 * kp + 1][r];
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            // lane 4q'+p of each 16-lane group addresses row q', columns 4p..4p+3 of its 4-key block
+            const int r0 = (2 * kp) * 16 + 4 * g + (li >> 2);
+            const int col = dt * 16 + 4 * (li & 3);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sV + r0 * ROWB + col * 2));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sV + (r0 + 16) * ROWB + col * 2));
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+        }
+    }
+    const float inv = 1.0f / sum;
+    bf16_t* orow = out + ((size_t)b * T + q) * inner + h * DKV;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const uint2 pk = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+        *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) = pk;
+    }
+}
+
+template <int T>
+int launch_t(const bf16_t* qkv, const float* bias_off, bf16_t* out, int B, int H, hipStream_t stream) {
+    const size_t lds = (size_t)2 * T * ROWB + (2 * T - 1) * sizeof(float) + 16;
+    if (qkv == nullptr)     // attribute-only call from init_enc_attn_kernels()
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -2;
+    enc_attn_kernel<T><<<dim3(T / 64, H, B), 256, lds, stream>>>(qkv, bias_off, out, H);
+    return 0;
+}
+
+}  // namespace
+
+int init_enc_attn_kernels() {
+    return launch_t<64>(nullptr, nullptr, nullptr, 1, 1, nullptr) | launch_t<128>(nullptr, nullptr, nullptr, 1, 1, nullptr) |
+           launch_t<256>(nullptr, nullptr, nullptr, 1, 1, nullptr) | launch_t<512>(nullptr, nullptr, nullptr, 1, 1, nullptr);
+}
+
+int launch_enc_attention(const bf16_t* qkv, const float* bias_off, bf16_t* out, int B, int T, int H, hipStream_t stream) {
+    if (B <= 0) return 0;
+    switch (T) {
+        case 64: return launch_t<64>(qkv, bias_off, out, B, H, stream);
+        case 128: return launch_t<128>(qkv, bias_off, out, B, H, stream);
+        case 256: return launch_t<256>(qkv, bias_off, out, B, H, stream);
+        case 512: return launch_t<512>(qkv, bias_off, out, B, H, stream);
+        default: return -1;
+    }
+}

@@ -1,0 +1,103 @@
+// Launcher declarations shared between the kernel translation units and runtime.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+// ---------------------------------------------------------------- front-end (frontend.hip)
+struct FrontendTables {
+    const float* window;      // [n_fft] periodic Hann
+    const float2* tw;         // [n_fft/2]   exp(-2 pi i m / (n_fft/2))
+    const float2* untw;       // [n_fft/2+1] exp(-2 pi i k / n_fft)
+    const int* mel_start;     // [n_mels] first bin of each triangle
+    const int* mel_len;       // [n_mels] bins in each triangle
+    const int* mel_off;       // [n_mels] offset into mel_w
+    const float* mel_w;       // concatenated triangle weights
+    int n_fft, hop, n_mels, n_samples, n_frames;
+    float log_floor;
+};
+int launch_logmel(const FrontendTables& t, const float* audio, float* mel, int B, hipStream_t stream);
+
+// ---------------------------------------------------------------- dense GEMM (gemm.hip)
+// C[M][N] (+)= A[M][K] (bf16, row stride lda) * W[N][K]^T (bf16, row stride ldw), fp32 accumulate.
+enum GemmEpilogue {
+    EPI_F32 = 0,          // out f32 [M][ldc] = acc (+ bias[n])
+    EPI_BF16 = 1,         // out bf16 [M][ldc] = R(acc)
+    EPI_BF16_RELU = 2,    // out bf16 [M][ldc] = R(max(acc, 0))
+    EPI_RESID = 3,        // out f32 [M][ldc] += acc
+    EPI_KV_HEADMAJOR = 4, // out bf16 [n / (H*64)][m / T][h][m % T][64]  (cross-attention K/V slabs)
+};
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* W; void* out; const float* bias;
+    int M, N, K, lda, ldw, ldc;
+    int T, H, n_seg;      // EPI_KV_HEADMAJOR only: frames per segment, heads, segments
+};
+int launch_gemm(int epilogue, const GemmArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------- norm / casts (norm.hip)
+// out bf16 [M][d] = R(x * rsqrt(mean(x^2) + eps) * gain)
+int launch_rmsnorm(const float* x, const float* gain, bf16_t* out, int M, int d, float eps, hipStream_t stream);
+int launch_f32_to_bf16(const float* x, bf16_t* out, size_t n, hipStream_t stream);
+
+// ---------------------------------------------------------------- encoder attention (enc_attn.hip)
+// qkv bf16 [B*T][3*H*64] -> out bf16 [B*T][H*64]; bias_off f32 [H][2T-1] indexed by key - query + T-1
+int init_enc_attn_kernels();
+int launch_enc_attention(const bf16_t* qkv, const float* bias_off, bf16_t* out, int B, int T, int H, hipStream_t stream);
+
+// ---------------------------------------------------------------- decoder step (decode.hip)
+struct DecodeShared {           // device-resident loop state, read by every decode kernel
+    int step;                   // position being decoded (tokens already in the cache)
+    int done_count;             // ticket counter of the argmax kernel
+    int n_steps;                // row stride of tokens_out / forced / logits_out
+    int pad0;
+    int32_t* tokens_out;        // [R][n_steps]
+    const int32_t* forced;      // [R][n_steps] or null
+    float* logits_out;          // [R][n_steps][V] or null
+};
+
+struct DecGemmArgs {
+    const float* x_f32;         // NORM variants: residual stream [R][K] fp32
+    const float* gain;          // NORM variants: [K]
+    const bf16_t* a_bf16;       // plain variants: [R][K] bf16
+    const bf16_t* W;            // [N][K] bf16
+    int R, N, K;
+    float eps;
+    // outputs (by mode)
+    bf16_t* out_bf16;           // [R][N] (MODE_BF16, MODE_BF16_RELU, q part of MODE_QKV_CACHE)
+    float* out_f32;             // [R][N] (MODE_RESID: +=, MODE_LOGITS: =)
+    bf16_t* kcache;             // MODE_QKV_CACHE: [R][H][L][64]
+    bf16_t* vcache;
+    int H, L;                   // cache geometry
+    const DecodeShared* shared; // MODE_QKV_CACHE reads shared->step
+};
+enum DecGemmMode { DG_NORM_QKV_CACHE = 0, DG_NORM_BF16 = 1, DG_NORM_BF16_RELU = 2, DG_NORM_LOGITS = 3, DG_RESID = 4 };
+int init_decode_kernels();
+int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream);
+
+struct DecAttnArgs {
+    const bf16_t* q;            // [R][H*64]
+    const bf16_t* k;            // slab base; slab (kv_row, h) at ((kv_row*H + h) * slab_keys) * 64
+    const bf16_t* v;
+    bf16_t* out;                // [R][H*64]
+    const float* bias;          // [H][L] by distance (self) or null (cross)
+    const DecodeShared* shared; // self: n_keys = shared->step + 1
+    int n_keys_const;           // cross: fixed key count
+    int slab_keys;              // keys allocated per (row, head) slab (L for self, T for cross)
+    int rows_per_kv;            // 1 for self; n_channels for cross (row r reads segment r / n_channels)
+    int R, H, bias_stride;
+};
+int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream);
+
+struct ArgmaxArgs {
+    const float* logits;        // [R][V]
+    float* h;                   // [R][d] residual stream to refill with the next embedding
+    const bf16_t* embed;        // [V][d]
+    const bf16_t* chan_embed;   // [K][d] or null
+    DecodeShared* shared;
+    int* finished;              // [R]
+    int R, V, d, n_channels, eos_id, pad_id;
+};
+int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream);
+// h[r] = embed[pad] (+ chan_embed), finished = 0, shared fields reset
+int launch_decode_init(const ArgmaxArgs& a, int n_steps, int32_t* tokens_out, const int32_t* forced, float* logits_out,
+                       hipStream_t stream);

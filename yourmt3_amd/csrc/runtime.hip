@@ -1,0 +1,449 @@
+// C-ABI runtime of the hot path: handle, weight blob, workspace, kernel orchestration, hipGraph
+// replay of the decode step.  Declarations and ownership rules: include/ymt3.h.
+//
+// Host logic only -- every FLOP is in frontend.hip / gemm.hip / norm.hip / enc_attn.hip /
+// decode.hip.  There is no CPU fallback: a missing device, tensor or unsupported shape is an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ymt3.h"
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void ymt3_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+#define FAIL(code, ...)              \
+    do {                             \
+        ymt3_set_error(__VA_ARGS__); \
+        return (code);               \
+    } while (0)
+#define LAUNCH(expr)                                                             \
+    do {                                                                         \
+        int _rc = (expr);                                                        \
+        if (_rc != 0) FAIL(YMT3_ERR_UNSUPPORTED, "%s rejected its shape (rc=%d)", #expr, _rc); \
+    } while (0)
+
+struct Tensor {
+    void* dev = nullptr;
+    uint32_t dtype = 0, ndim = 0, shape[4] = {1, 1, 1, 1};
+    size_t nbytes = 0;
+};
+
+struct StepGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct ymt3_ctx {
+    ymt3_config cfg{};
+    int device = 0;
+    int T = 0, inner = 0, maxB = 0, maxR = 0;
+    char* blob_dev = nullptr;
+    size_t blob_bytes = 0;
+    std::map<std::string, Tensor> tensors;
+    std::vector<void*> allocs;
+    size_t dev_bytes = 0;
+    FrontendTables fe{};
+    // encoder workspace
+    float* mel = nullptr;
+    bf16_t* mel_bf = nullptr;
+    float* h_enc = nullptr;
+    bf16_t *xn = nullptr, *qkv = nullptr, *attn = nullptr, *ff = nullptr, *enc_out = nullptr;
+    // decoder workspace
+    bf16_t* wkv_all = nullptr;          // [n_dec*2*inner][d]
+    bf16_t* ckv = nullptr;              // [n_dec*2][B][H][T][64]
+    bf16_t *kcache = nullptr, *vcache = nullptr;   // [n_dec][maxR][H][L][64]
+    float* h_dec = nullptr;
+    bf16_t *dq = nullptr, *dattn = nullptr, *dff = nullptr;
+    float* logits = nullptr;
+    int* finished = nullptr;
+    DecodeShared* shared = nullptr;
+    hipStream_t cap_stream = nullptr;
+    std::map<int, StepGraph> step_graphs;   // keyed by B
+    bool use_graph = true;
+};
+
+static int dev_alloc(ymt3_ctx* c, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    c->allocs.push_back(*p);
+    c->dev_bytes += bytes;
+    return 0;
+}
+
+template <typename T>
+static int get(ymt3_ctx* c, const std::string& name, uint32_t dtype, T** out, size_t min_elems = 0) {
+    auto it = c->tensors.find(name);
+    if (it == c->tensors.end()) FAIL(YMT3_ERR_BLOB, "weight blob has no tensor '%s'", name.c_str());
+    if (it->second.dtype != dtype) FAIL(YMT3_ERR_BLOB, "tensor '%s' has dtype %u, expected %u", name.c_str(), it->second.dtype, dtype);
+    const size_t esz = dtype == 1 ? 2 : 4;
+    if (it->second.nbytes < min_elems * esz)
+        FAIL(YMT3_ERR_BLOB, "tensor '%s' holds %zu bytes, expected at least %zu", name.c_str(), it->second.nbytes, min_elems * esz);
+    *out = reinterpret_cast<T*>(it->second.dev);
+    return 0;
+}
+#define GET(...)                     \
+    do {                             \
+        int _rc = get(__VA_ARGS__);  \
+        if (_rc) return _rc;         \
+    } while (0)
+
+#pragma pack(push, 1)
+struct BlobEntry {
+    char name[48];
+    uint32_t dtype, ndim, shape[4];
+    uint64_t offset, nbytes;
+};
+#pragma pack(pop)
+static_assert(sizeof(BlobEntry) == 88, "blob entry layout");
+
+static int parse_blob(ymt3_ctx* c, const void* blob, size_t nbytes) {
+    const char* b = static_cast<const char*>(blob);
+    if (nbytes < 16 || memcmp(b, "YMT3BLOB", 8) != 0) FAIL(YMT3_ERR_BLOB, "bad weight blob magic");
+    uint32_t ver, n;
+    memcpy(&ver, b + 8, 4);
+    memcpy(&n, b + 12, 4);
+    if (ver != 1) FAIL(YMT3_ERR_BLOB, "unsupported blob version %u", ver);
+    if (16 + (size_t)n * sizeof(BlobEntry) > nbytes) FAIL(YMT3_ERR_BLOB, "truncated blob header");
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->blob_dev), nbytes));
+    c->allocs.push_back(c->blob_dev);
+    c->dev_bytes += nbytes;
+    c->blob_bytes = nbytes;
+    HIP_TRY(hipMemcpy(c->blob_dev, blob, nbytes, hipMemcpyHostToDevice));
+    for (uint32_t i = 0; i < n; ++i) {
+        BlobEntry e;
+        memcpy(&e, b + 16 + (size_t)i * sizeof(BlobEntry), sizeof(e));
+        if (e.offset % 16 || e.offset + e.nbytes > nbytes) FAIL(YMT3_ERR_BLOB, "tensor %u out of bounds / misaligned", i);
+        e.name[47] = 0;
+        Tensor t;
+        t.dev = c->blob_dev + e.offset;
+        t.dtype = e.dtype;
+        t.ndim = e.ndim;
+        memcpy(t.shape, e.shape, sizeof(t.shape));
+        t.nbytes = e.nbytes;
+        c->tensors[e.name] = t;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ymt3_abi_version(void) { return YMT3_ABI_VERSION; }
+extern "C" const char* ymt3_last_error(void) { return g_err; }
+
+extern "C" void ymt3_destroy(ymt3_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (auto& kv : h->step_graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" size_t ymt3_device_bytes(ymt3_handle h) { return h ? h->dev_bytes : 0; }
+
+static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, size_t nbytes) {
+    const ymt3_config& k = c->cfg;
+    if (k.d_kv != 64) FAIL(YMT3_ERR_UNSUPPORTED, "d_kv must be 64 (got %d)", k.d_kv);
+    if (k.d_model != 512) FAIL(YMT3_ERR_UNSUPPORTED, "d_model must be 512 (got %d)", k.d_model);
+    if (k.n_heads * k.d_kv != 512) FAIL(YMT3_ERR_UNSUPPORTED, "n_heads*d_kv must be 512");
+    if (k.encoder_type != YMT3_ENC_T5) FAIL(YMT3_ERR_UNSUPPORTED, "encoder_type %d not built yet", k.encoder_type);
+    if (k.dec_ffn != YMT3_FFN_DENSE) FAIL(YMT3_ERR_UNSUPPORTED, "dec_ffn %d not built yet", k.dec_ffn);
+    if (k.max_batch <= 0 || k.n_channels <= 0 || k.max_decode_len <= 0) FAIL(YMT3_ERR_ARG, "bad max_batch / n_channels / max_decode_len");
+    c->T = 1 + k.segment_samples / k.hop;
+    c->inner = k.n_heads * k.d_kv;
+    c->maxB = k.max_batch;
+    c->maxR = k.max_batch * k.n_channels;
+    if (c->T % 64) FAIL(YMT3_ERR_UNSUPPORTED, "n_frames must be a multiple of 64 (got %d)", c->T);
+    if (k.vocab % 16 || k.d_ff % 128) FAIL(YMT3_ERR_UNSUPPORTED, "vocab %% 16 and d_ff %% 128 must be 0");
+
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = parse_blob(c, blob, nbytes);
+    if (rc) return rc;
+    if (init_enc_attn_kernels() || init_decode_kernels()) FAIL(YMT3_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+
+    // front-end tables (built by yourmt3_amd/tables.py, carried in the blob)
+    const int nfft = k.n_fft;
+    FrontendTables& fe = c->fe;
+    GET(c, "fe.window", 0u, const_cast<float**>(&fe.window), (size_t)nfft);
+    GET(c, "fe.tw", 0u, reinterpret_cast<float**>(const_cast<float2**>(&fe.tw)), (size_t)nfft);
+    GET(c, "fe.untw", 0u, reinterpret_cast<float**>(const_cast<float2**>(&fe.untw)), (size_t)nfft + 2);
+    GET(c, "fe.mel_start", 2u, const_cast<int**>(&fe.mel_start), (size_t)k.n_mels);
+    GET(c, "fe.mel_len", 2u, const_cast<int**>(&fe.mel_len), (size_t)k.n_mels);
+    GET(c, "fe.mel_off", 2u, const_cast<int**>(&fe.mel_off), (size_t)k.n_mels);
+    GET(c, "fe.mel_w", 0u, const_cast<float**>(&fe.mel_w), 1);
+    fe.n_fft = nfft; fe.hop = k.hop; fe.n_mels = k.n_mels; fe.n_samples = k.segment_samples;
+    fe.n_frames = c->T; fe.log_floor = k.log_floor;
+    if (nfft != 2048 && nfft != 512) FAIL(YMT3_ERR_UNSUPPORTED, "n_fft must be 2048 or 512");
+    if (k.n_mels % 64) FAIL(YMT3_ERR_UNSUPPORTED, "n_mels must be a multiple of 64");
+
+    const size_t BT = (size_t)c->maxB * c->T, d = k.d_model, R = c->maxR;
+    if (dev_alloc(c, (void**)&c->mel, BT * k.n_mels * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->mel_bf, BT * k.n_mels * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->h_enc, BT * d * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->xn, BT * d * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->qkv, BT * 3 * c->inner * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->attn, BT * c->inner * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->ff, BT * k.d_ff * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->enc_out, BT * d * 2)) return YMT3_ERR_HIP;
+
+    const int nd = k.n_dec_layers;
+    const size_t wkv_elems = (size_t)2 * c->inner * d;
+    if (dev_alloc(c, (void**)&c->wkv_all, nd * wkv_elems * 2)) return YMT3_ERR_HIP;
+    for (int l = 0; l < nd; ++l) {
+        bf16_t* src;
+        GET(c, "dec." + std::to_string(l) + ".wkv_c", 1u, &src, wkv_elems);
+        HIP_TRY(hipMemcpy(c->wkv_all + l * wkv_elems, src, wkv_elems * 2, hipMemcpyDeviceToDevice));
+    }
+    if (dev_alloc(c, (void**)&c->ckv, (size_t)nd * 2 * BT * c->inner * 2)) return YMT3_ERR_HIP;
+    const size_t cache_elems = (size_t)nd * R * k.n_heads * k.max_decode_len * 64;
+    if (dev_alloc(c, (void**)&c->kcache, cache_elems * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->vcache, cache_elems * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->h_dec, R * d * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->dq, R * c->inner * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->dattn, R * c->inner * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->dff, R * k.d_ff * 2)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->logits, R * k.vocab * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->finished, R * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->shared, sizeof(DecodeShared))) return YMT3_ERR_HIP;
+    HIP_TRY(hipMemset(c->shared, 0, sizeof(DecodeShared)));
+    HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    const char* ng = getenv("YMT3_NO_GRAPH");
+    c->use_graph = !(ng && ng[0] == '1');
+
+    // every tensor the kernels will ask for must be present now, not at the first call
+    const char* enc_names[] = {"ln1", "wqkv", "wo", "ln2", "wi", "wo2"};
+    for (int l = 0; l < k.n_enc_layers; ++l)
+        for (const char* n : enc_names)
+            if (!c->tensors.count("enc." + std::to_string(l) + "." + n)) FAIL(YMT3_ERR_BLOB, "missing enc.%d.%s", l, n);
+    const char* dec_names[] = {"ln1", "wqkv", "wo", "ln2", "wq_c", "wo_c", "ln3", "wi", "wo2"};
+    for (int l = 0; l < nd; ++l)
+        for (const char* n : dec_names)
+            if (!c->tensors.count("dec." + std::to_string(l) + "." + n)) FAIL(YMT3_ERR_BLOB, "missing dec.%d.%s", l, n);
+    HIP_TRY(hipDeviceSynchronize());
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_create(const ymt3_config* cfg, const void* blob, size_t nbytes, int device, ymt3_handle* out) {
+    if (!cfg || !blob || !out) FAIL(YMT3_ERR_ARG, "null argument to ymt3_create");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(YMT3_ERR_HIP, "no HIP device visible: the HIP path cannot run (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) FAIL(YMT3_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    ymt3_ctx* c = new ymt3_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    int rc = create_impl(c, cfg, blob, nbytes);
+    if (rc != YMT3_OK) {
+        ymt3_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return YMT3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int check_call(ymt3_handle h, int B) {
+    if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (B < 0 || B > h->maxB) FAIL(YMT3_ERR_ARG, "B=%d outside [0, max_batch=%d]", B, h->maxB);
+    HIP_TRY(hipSetDevice(h->device));
+    return 0;
+}
+
+extern "C" int ymt3_logmel(ymt3_handle h, const float* audio_dev, int B, float* mel_dev, void* stream) {
+    int rc = check_call(h, B);
+    if (rc) return rc;
+    if (B == 0) return YMT3_OK;
+    if (!audio_dev || !mel_dev) FAIL(YMT3_ERR_ARG, "null buffer");
+    LAUNCH(launch_logmel(h->fe, audio_dev, mel_dev, B, (hipStream_t)stream));
+    HIP_TRY(hipGetLastError());
+    return YMT3_OK;
+}
+
+static int encode_impl(ymt3_handle h, const float* mel, int B, bf16_t* enc_out, hipStream_t s) {
+    const ymt3_config& k = h->cfg;
+    const int M = B * h->T, d = k.d_model, inner = h->inner;
+    LAUNCH(launch_f32_to_bf16(mel, h->mel_bf, (size_t)M * k.n_mels, s));
+    bf16_t* w;
+    float* f;
+    {
+        float* bias;
+        GET(h, "in_proj.w", 1u, &w, (size_t)d * k.n_mels);
+        GET(h, "in_proj.b", 0u, &bias, (size_t)d);
+        GemmArgs g{h->mel_bf, w, h->h_enc, bias, M, d, k.n_mels, k.n_mels, k.n_mels, d, 0, 0, 0};
+        LAUNCH(launch_gemm(EPI_F32, g, s));
+    }
+    const float* bias_off;
+    GET(h, "enc.bias_off", 0u, const_cast<float**>(&bias_off), (size_t)k.n_heads * (2 * h->T - 1));
+    for (int l = 0; l < k.n_enc_layers; ++l) {
+        const std::string p = "enc." + std::to_string(l) + ".";
+        GET(h, p + "ln1", 0u, &f, (size_t)d);
+        LAUNCH(launch_rmsnorm(h->h_enc, f, h->xn, M, d, k.ln_eps, s));
+        GET(h, p + "wqkv", 1u, &w, (size_t)3 * inner * d);
+        { GemmArgs g{h->xn, w, h->qkv, nullptr, M, 3 * inner, d, d, d, 3 * inner, 0, 0, 0}; LAUNCH(launch_gemm(EPI_BF16, g, s)); }
+        LAUNCH(launch_enc_attention(h->qkv, bias_off, h->attn, B, h->T, k.n_heads, s));
+        GET(h, p + "wo", 1u, &w, (size_t)d * inner);
+        { GemmArgs g{h->attn, w, h->h_enc, nullptr, M, d, inner, inner, inner, d, 0, 0, 0}; LAUNCH(launch_gemm(EPI_RESID, g, s)); }
+        GET(h, p + "ln2", 0u, &f, (size_t)d);
+        LAUNCH(launch_rmsnorm(h->h_enc, f, h->xn, M, d, k.ln_eps, s));
+        GET(h, p + "wi", 1u, &w, (size_t)k.d_ff * d);
+        { GemmArgs g{h->xn, w, h->ff, nullptr, M, k.d_ff, d, d, d, k.d_ff, 0, 0, 0}; LAUNCH(launch_gemm(EPI_BF16_RELU, g, s)); }
+        GET(h, p + "wo2", 1u, &w, (size_t)d * k.d_ff);
+        { GemmArgs g{h->ff, w, h->h_enc, nullptr, M, d, k.d_ff, k.d_ff, k.d_ff, d, 0, 0, 0}; LAUNCH(launch_gemm(EPI_RESID, g, s)); }
+    }
+    GET(h, "enc.ln_f", 0u, &f, (size_t)d);
+    LAUNCH(launch_rmsnorm(h->h_enc, f, enc_out, M, d, k.ln_eps, s));
+    HIP_TRY(hipGetLastError());
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_encode(ymt3_handle h, const float* mel_dev, int B, void* enc_dev, void* stream) {
+    int rc = check_call(h, B);
+    if (rc) return rc;
+    if (B == 0) return YMT3_OK;
+    if (!mel_dev || !enc_dev) FAIL(YMT3_ERR_ARG, "null buffer");
+    return encode_impl(h, mel_dev, B, static_cast<bf16_t*>(enc_dev), (hipStream_t)stream);
+}
+
+// one decoder step = 8 kernels per layer + lm_head + argmax, all reading the position from h->shared
+static int launch_step(ymt3_handle h, int B, hipStream_t s) {
+    const ymt3_config& k = h->cfg;
+    const int R = B * k.n_channels, d = k.d_model, inner = h->inner, H = k.n_heads, L = k.max_decode_len;
+    const size_t layer_cache = (size_t)h->maxR * H * L * 64;
+    const size_t slab = (size_t)B * H * h->T * 64;
+    const float* bias_dist;
+    GET(h, "dec.bias_dist", 0u, const_cast<float**>(&bias_dist), (size_t)H * L);
+    bf16_t* w;
+    float* f;
+    for (int l = 0; l < k.n_dec_layers; ++l) {
+        const std::string p = "dec." + std::to_string(l) + ".";
+        DecGemmArgs a{};
+        a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = h->shared;
+        // self-attention block
+        GET(h, p + "ln1", 0u, &f, (size_t)d);
+        GET(h, p + "wqkv", 1u, &w, (size_t)3 * inner * d);
+        a.x_f32 = h->h_dec; a.gain = f; a.W = w; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
+        a.kcache = h->kcache + l * layer_cache; a.vcache = h->vcache + l * layer_cache;
+        LAUNCH(launch_dec_gemm(DG_NORM_QKV_CACHE, a, s));
+        DecAttnArgs t{};
+        t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = h->shared;
+        t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
+        LAUNCH(launch_dec_attention(true, t, s));
+        GET(h, p + "wo", 1u, &w, (size_t)d * inner);
+        a.a_bf16 = h->dattn; a.W = w; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
+        LAUNCH(launch_dec_gemm(DG_RESID, a, s));
+        // cross-attention block
+        GET(h, p + "ln2", 0u, &f, (size_t)d);
+        GET(h, p + "wq_c", 1u, &w, (size_t)inner * d);
+        a.gain = f; a.W = w; a.N = inner; a.K = d; a.out_bf16 = h->dq;
+        LAUNCH(launch_dec_gemm(DG_NORM_BF16, a, s));
+        t.k = h->ckv + (size_t)(2 * l) * slab; t.v = h->ckv + (size_t)(2 * l + 1) * slab; t.bias = nullptr;
+        t.n_keys_const = h->T; t.slab_keys = h->T; t.rows_per_kv = k.n_channels;
+        LAUNCH(launch_dec_attention(false, t, s));
+        GET(h, p + "wo_c", 1u, &w, (size_t)d * inner);
+        a.a_bf16 = h->dattn; a.W = w; a.N = d; a.K = inner;
+        LAUNCH(launch_dec_gemm(DG_RESID, a, s));
+        // feed-forward block
+        GET(h, p + "ln3", 0u, &f, (size_t)d);
+        GET(h, p + "wi", 1u, &w, (size_t)k.d_ff * d);
+        a.gain = f; a.W = w; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
+        LAUNCH(launch_dec_gemm(DG_NORM_BF16_RELU, a, s));
+        GET(h, p + "wo2", 1u, &w, (size_t)d * k.d_ff);
+        a.a_bf16 = h->dff; a.W = w; a.N = d; a.K = k.d_ff;
+        LAUNCH(launch_dec_gemm(DG_RESID, a, s));
+    }
+    DecGemmArgs a{};
+    a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = h->shared;
+    GET(h, "dec.ln_f", 0u, &f, (size_t)d);
+    GET(h, "dec.lm_head", 1u, &w, (size_t)k.vocab * d);
+    a.x_f32 = h->h_dec; a.gain = f; a.W = w; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
+    LAUNCH(launch_dec_gemm(DG_NORM_LOGITS, a, s));
+    ArgmaxArgs g{};
+    g.logits = h->logits; g.h = h->h_dec; g.shared = h->shared; g.finished = h->finished;
+    g.R = R; g.V = k.vocab; g.d = d; g.n_channels = k.n_channels; g.eos_id = k.eos_id; g.pad_id = k.pad_id;
+    GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&g.embed), (size_t)k.vocab * d);
+    if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&g.chan_embed), (size_t)k.n_channels * d);
+    LAUNCH(launch_argmax_embed(g, s));
+    return YMT3_OK;
+}
+
+static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int32_t* tokens, const int32_t* forced,
+                       float* logits_out, hipStream_t s) {
+    const ymt3_config& k = h->cfg;
+    if (n_steps <= 0 || n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len);
+    const int d = k.d_model, R = B * k.n_channels;
+    // a6: cross-attention K/V of every decoder layer in one GEMM, stored as per-(segment, head) slabs
+    GemmArgs g{enc, h->wkv_all, h->ckv, nullptr, B * h->T, k.n_dec_layers * 2 * h->inner, d, d, d, 0, h->T, k.n_heads, B};
+    LAUNCH(launch_gemm(EPI_KV_HEADMAJOR, g, s));
+
+    ArgmaxArgs a{};
+    a.h = h->h_dec; a.shared = h->shared; a.finished = h->finished;
+    a.R = R; a.V = k.vocab; a.d = d; a.n_channels = k.n_channels; a.eos_id = k.eos_id; a.pad_id = k.pad_id;
+    GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&a.embed), (size_t)k.vocab * d);
+    if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&a.chan_embed), (size_t)k.n_channels * d);
+    LAUNCH(launch_decode_init(a, n_steps, tokens, forced, logits_out, s));
+
+    if (!h->use_graph) {
+        for (int t = 0; t < n_steps; ++t) {
+            int rc = launch_step(h, B, s);
+            if (rc) return rc;
+        }
+    } else {
+        StepGraph& sg = h->step_graphs[B];
+        if (!sg.exec) {
+            HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = launch_step(h, B, h->cap_stream);
+            hipError_t e = hipStreamEndCapture(h->cap_stream, &sg.graph);
+            if (rc) return rc;
+            if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIP_TRY(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+        }
+        for (int t = 0; t < n_steps; ++t) HIP_TRY(hipGraphLaunch(sg.exec, s));
+    }
+    HIP_TRY(hipGetLastError());
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_decode_greedy(ymt3_handle h, const void* enc_dev, int B, int n_steps, int32_t* tokens_dev,
+                                  const int32_t* forced_dev, float* logits_dev, void* stream) {
+    int rc = check_call(h, B);
+    if (rc) return rc;
+    if (B == 0) return YMT3_OK;
+    if (!enc_dev || !tokens_dev) FAIL(YMT3_ERR_ARG, "null buffer");
+    return decode_impl(h, static_cast<const bf16_t*>(enc_dev), B, n_steps, tokens_dev, forced_dev, logits_dev, (hipStream_t)stream);
+}
+
+extern "C" int ymt3_transcribe_segments(ymt3_handle h, const float* audio_dev, int B, int n_steps, int32_t* tokens_dev,
+                                        void* stream) {
+    int rc = check_call(h, B);
+    if (rc) return rc;
+    if (B == 0) return YMT3_OK;
+    if (!audio_dev || !tokens_dev) FAIL(YMT3_ERR_ARG, "null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(launch_logmel(h->fe, audio_dev, h->mel, B, s));
+    rc = encode_impl(h, h->mel, B, h->enc_out, s);
+    if (rc) return rc;
+    return decode_impl(h, h->enc_out, B, n_steps, tokens_dev, nullptr, nullptr, s);
+}
+
+extern "C" int ymt3_test_gemm(ymt3_handle h, const void* a_dev, const void* w_dev, float* c_dev, int M, int N, int K, void* stream) {
+    int rc = check_call(h, 0);
+    if (rc) return rc;
+    GemmArgs g{static_cast<const bf16_t*>(a_dev), static_cast<const bf16_t*>(w_dev), c_dev, nullptr, M, N, K, K, K, N, 0, 0, 0};
+    LAUNCH(launch_gemm(EPI_F32, g, (hipStream_t)stream));
+    HIP_TRY(hipGetLastError());
+    return YMT3_OK;
+}

@@ -1,0 +1,123 @@
+"""Host-side mirror of the model object on the reference's inference path.
+
+SURVEY.md section 9 (unverified recollection; nothing in /root/reference to cite) has upstream
+`model/ymt3.py` exposing `inference(x, task_tokens, max_token_length)` and
+`inference_file(bsz, audio_segments)` returning a list of (B, K, L) int arrays.  `YourMT3` keeps
+those names and shapes; every tensor operation is a call through the C ABI (include/ymt3.h) into
+the gfx950 kernels.  torch is used for device buffers and the current HIP stream only.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import YMT3Config, to_c
+from .tables import derived_tables
+from .weights import make_weights, pack_blob
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class YourMT3:
+    def __init__(self, cfg: YMT3Config, weights: Optional[Dict[str, torch.Tensor]] = None, *, seed: int = 1234,
+                 device: int = 0, max_batch: int = 64):
+        if not torch.cuda.is_available():
+            raise _lib.YMT3Error("no GPU visible: the MI355X HIP path cannot run (there is no CPU fallback)")
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self.max_batch = int(max_batch)
+        self._lib = _lib.load()
+        self.weights = weights if weights is not None else make_weights(cfg, seed)
+        blob = pack_blob({**self.weights, **derived_tables(self.weights, cfg)})
+        self._handle = ctypes.c_void_p()
+        ccfg = to_c(cfg, self.max_batch)
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        _lib.check(self._lib.ymt3_create(ctypes.byref(ccfg), buf, len(blob), device, ctypes.byref(self._handle)))
+
+    def close(self):
+        if getattr(self, "_handle", None) and self._handle.value:
+            self._lib.ymt3_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def device_bytes(self) -> int:
+        return int(self._lib.ymt3_device_bytes(self._handle))
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _audio2d(self, audio: torch.Tensor) -> torch.Tensor:
+        if audio.dim() == 3:                       # (B, 1, S) as upstream slices it
+            audio = audio[:, 0, :]
+        if audio.shape[-1] != self.cfg.segment_samples:
+            raise ValueError(f"segments must have {self.cfg.segment_samples} samples, got {audio.shape[-1]}")
+        if audio.shape[0] > self.max_batch:
+            raise ValueError(f"batch {audio.shape[0]} exceeds max_batch {self.max_batch}")
+        return audio.to(self.device, torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ stages (C ABI, 1:1)
+    def logmel(self, audio: torch.Tensor) -> torch.Tensor:
+        a = self._audio2d(audio)
+        B = a.shape[0]
+        mel = torch.empty(B, self.cfg.n_frames, self.cfg.n_mels, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.ymt3_logmel(self._handle, _ptr(a), B, _ptr(mel), self._stream()))
+        return mel
+
+    def encode(self, mel: torch.Tensor) -> torch.Tensor:
+        mel = mel.to(self.device, torch.float32).contiguous()
+        B = mel.shape[0]
+        enc = torch.empty(B, self.cfg.n_frames, self.cfg.d_model, device=self.device, dtype=torch.bfloat16)
+        _lib.check(self._lib.ymt3_encode(self._handle, _ptr(mel), B, _ptr(enc), self._stream()))
+        return enc
+
+    def decode(self, enc: torch.Tensor, n_steps: Optional[int] = None, forced: Optional[torch.Tensor] = None,
+               return_logits: bool = False):
+        cfg = self.cfg
+        n_steps = int(n_steps or cfg.max_decode_len)
+        enc = enc.to(self.device, torch.bfloat16).contiguous()
+        B = enc.shape[0]
+        tokens = torch.empty(B, cfg.n_channels, n_steps, device=self.device, dtype=torch.int32)
+        f = forced.to(self.device, torch.int32).contiguous() if forced is not None else None
+        if f is not None and tuple(f.shape) != (B, cfg.n_channels, n_steps):
+            raise ValueError("forced must be (B, n_channels, n_steps)")
+        lg = torch.empty(B, cfg.n_channels, n_steps, cfg.vocab, device=self.device, dtype=torch.float32) if return_logits else None
+        _lib.check(self._lib.ymt3_decode_greedy(self._handle, _ptr(enc), B, n_steps, _ptr(tokens), _ptr(f), _ptr(lg), self._stream()))
+        return (tokens, lg) if return_logits else tokens
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def inference(self, audio: torch.Tensor, task_tokens=None, max_token_length: Optional[int] = None) -> torch.Tensor:
+        """(B, 1, S) or (B, S) audio -> (B, K, L) int32 token ids: the whole hot path, one C call."""
+        a = self._audio2d(audio)
+        B = a.shape[0]
+        L = int(max_token_length or self.cfg.max_decode_len)
+        tokens = torch.empty(B, self.cfg.n_channels, L, device=self.device, dtype=torch.int32)
+        _lib.check(self._lib.ymt3_transcribe_segments(self._handle, _ptr(a), B, L, _ptr(tokens), self._stream()))
+        return tokens
+
+    def inference_file(self, bsz: int, audio_segments: torch.Tensor, max_token_length: Optional[int] = None) -> List[np.ndarray]:
+        """Split (N, 1, S) segments into batches of `bsz`; one (b, K, L) int array per batch."""
+        bsz = min(int(bsz), self.max_batch)
+        out = []
+        for i in range(0, audio_segments.shape[0], bsz):
+            out.append(self.inference(audio_segments[i:i + bsz], max_token_length=max_token_length).cpu().numpy())
+        return out
+
+    def test_gemm(self, a_bf16: torch.Tensor, w_bf16: torch.Tensor) -> torch.Tensor:
+        M, K = a_bf16.shape
+        N = w_bf16.shape[0]
+        c = torch.empty(M, N, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.ymt3_test_gemm(self._handle, _ptr(a_bf16.contiguous()), _ptr(w_bf16.contiguous()), _ptr(c), M, N, K, self._stream()))
+        return c
