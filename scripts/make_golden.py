@@ -1,0 +1,57 @@
+"""Generate tests/golden/*.npz from the CPU oracle (bf16-emulating mode = the HIP numerics contract).
+
+The reference tree holds no fixtures (parity unpinned), so these vectors are produced by
+this build's own oracle, which tests/test_oracle_vs_thirdparty.py pins against torch.stft and HF T5.
+Run:  python scripts/make_golden.py      (CPU only, ~1 min)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ymt3_oracle as O                     # noqa: E402
+from yourmt3_amd.config import YMT3Config               # noqa: E402
+from yourmt3_amd.weights import make_weights, f32_to_bf16_bits  # noqa: E402
+
+CASES = {
+    "small_t64": (YMT3Config(segment_samples=8191, max_decode_len=64), 2, 48),
+    "full_t256": (YMT3Config(max_decode_len=128), 2, 128),
+    "mc3_t64": (YMT3Config(segment_samples=8191, max_decode_len=32, n_channels=3), 2, 24),
+}
+LOGIT_STEPS = (0, 1, 23)
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, (cfg, B, n_steps) in CASES.items():
+        W = make_weights(cfg, seed=1234)
+        audio = O.synthetic_audio(B, cfg, seed=0)
+        mel, enc = O.encode(audio, W, cfg, bf16=True)
+        toks, logits = O.greedy_decode(enc, W, cfg, n_steps, bf16=True, return_logits=True)
+        top2 = logits.topk(2, -1).values
+        margin = (top2[..., 0] - top2[..., 1]).numpy().astype(np.float32)
+        np.savez_compressed(
+            os.path.join(out_dir, name + ".npz"),
+            mel=mel.numpy().astype(np.float32),
+            enc_bf16=f32_to_bf16_bits(enc),
+            tokens=toks.numpy().astype(np.int32),
+            margin=margin,
+            logit_steps=np.array(LOGIT_STEPS, dtype=np.int32),
+            logits=logits[:, :, list(LOGIT_STEPS), :].numpy().astype(np.float32),
+            n_steps=np.int32(n_steps), seed_weights=np.int32(1234), seed_audio=np.int32(0),
+        )
+        print(name, "tokens", toks.shape, "distinct", len(set(toks.flatten().tolist())), "min margin", float(margin.min()))
+    # integer relative-position bucket tables (a5), both directions
+    q = np.arange(512)[:, None]
+    k = np.arange(512)[None, :]
+    np.savez_compressed(os.path.join(out_dir, "relpos_buckets.npz"),
+                        bidirectional=O.relative_position_bucket(k - q, True, 32, 128).astype(np.int8),
+                        causal=O.relative_position_bucket(k - q, False, 32, 128).astype(np.int8))
+
+
+if __name__ == "__main__":
+    main()

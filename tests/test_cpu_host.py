@@ -1,0 +1,159 @@
+"""CPU-side tests: ABI surface, blob format, host tables, golden fixtures vs the oracle, sharding."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ymt3_oracle as O
+from yourmt3_amd import tables
+from yourmt3_amd.config import YMT3Config, CConfig, baseline_config
+from yourmt3_amd.weights import make_weights, pack_blob, unpack_blob, f32_to_bf16_bits, bf16_bits_to_f32
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_builds_loads_and_exports_every_header_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from yourmt3_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "ymt3.h")).read()
+    declared = set(re.findall(r"\b(ymt3_[a-z_0-9]+)\s*\(", header))
+    declared -= {"ymt3_ctx"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.ymt3_abi_version() == 1
+
+
+def test_cconfig_matches_header_field_order():
+    header = open(os.path.join(ROOT, "include", "ymt3.h")).read()
+    body = header[header.index("typedef struct ymt3_config {"):header.index("} ymt3_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for line in body.splitlines()[1:]:
+        m = re.match(r"\s*(int32_t|float)\s+(.*);", line)
+        if m:
+            fields += [(f.strip(), m.group(1)) for f in m.group(2).split(",")]
+    py = [(n, "float" if t is ctypes.c_float else "int32_t") for n, t in CConfig._fields_]
+    assert fields == py
+    assert ctypes.sizeof(CConfig) == 4 * len(py)
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from yourmt3_amd._lib import YMT3Error
+    from yourmt3_amd.model import YourMT3
+    with pytest.raises(YMT3Error):
+        YourMT3(YMT3Config(segment_samples=8191))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "yourmt3_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_blob_roundtrip_and_bf16_rounding():
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=16)
+    W = make_weights(cfg)
+    W2 = unpack_blob(pack_blob({**W, **tables.derived_tables(W, cfg)}))
+    for k, v in W.items():
+        assert torch.equal(v, W2[k]), k
+    assert W2["fe.mel_start"].dtype == torch.int32
+    x = torch.tensor([1.0, 1.00390625, 1.005859375, -3.1415926, 65504.0, 1e-40])
+    assert torch.equal(bf16_bits_to_f32(f32_to_bf16_bits(x)), x.bfloat16().float())   # RNE, ties to even
+
+
+def test_bucket_tables_match_oracle_hf_and_golden():
+    z = np.load(os.path.join(GOLD, "relpos_buckets.npz"))
+    q = np.arange(512)[:, None]
+    k = np.arange(512)[None, :]
+    for key, bidir in (("bidirectional", True), ("causal", False)):
+        got = tables.relative_position_bucket(k - q, bidir, 32, 128)
+        assert np.array_equal(got, z[key].astype(np.int64))
+        assert np.array_equal(got, O.relative_position_bucket(k - q, bidir, 32, 128))
+    cfg = YMT3Config()
+    W = make_weights(cfg)
+    assert torch.equal(tables.encoder_bias_table(W["enc.relbias"], 256, cfg), O.encoder_bias_by_offset(W["enc.relbias"], 256, cfg))
+    assert torch.equal(tables.decoder_bias_table(W["dec.relbias"], 1024, cfg), O.decoder_bias_by_distance(W["dec.relbias"], 1024, cfg))
+
+
+def test_frontend_tables_reproduce_the_oracle_filterbank():
+    cfg = YMT3Config()
+    t = tables.frontend_tables(cfg)
+    fb = O.mel_filterbank_htk(cfg.n_mels, cfg.n_fft, cfg.sample_rate, cfg.f_min, cfg.f_max)
+    dense = torch.zeros_like(fb)
+    for m in range(cfg.n_mels):
+        s, n, o = int(t["fe.mel_start"][m]), int(t["fe.mel_len"][m]), int(t["fe.mel_off"][m])
+        dense[m, s:s + n] = t["fe.mel_w"][o:o + n]
+    assert torch.equal(dense, fb)
+    assert torch.allclose(t["fe.window"], O.hann_window(cfg.n_fft), atol=1e-7)
+    assert t["fe.tw"].shape == (cfg.n_fft // 2, 2) and t["fe.untw"].shape == (cfg.n_fft // 2 + 1, 2)
+
+
+@pytest.mark.parametrize("name,cfg,n", [
+    ("small_t64", YMT3Config(segment_samples=8191, max_decode_len=64), 48),
+    ("mc3_t64", YMT3Config(segment_samples=8191, max_decode_len=32, n_channels=3), 24),
+])
+def test_oracle_reproduces_golden_fixture(name, cfg, n):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    W = make_weights(cfg, seed=int(z["seed_weights"]))
+    a = O.synthetic_audio(2, cfg, seed=int(z["seed_audio"]))
+    mel, enc = O.encode(a, W, cfg, True)
+    assert np.allclose(mel.numpy(), z["mel"], atol=1e-5)
+    assert np.array_equal(f32_to_bf16_bits(enc), z["enc_bf16"])
+    toks = O.greedy_decode(enc, W, cfg, n, True)
+    assert np.array_equal(toks.numpy(), z["tokens"])
+
+
+def test_baseline_configs():
+    assert baseline_config(1).eos_id == -1 and baseline_config(1).max_decode_len == 1024
+    assert baseline_config(3).n_channels == 13 and baseline_config(3).max_decode_len == 256
+    assert baseline_config(0).n_frames == 256 and abs(baseline_config(0).segment_seconds - 2.048) < 1e-9
+
+
+def test_shard_ranges_cover_every_segment_once():
+    from yourmt3_amd.dist import shard_range, shard_sizes
+    for n in (0, 1, 7, 64, 65, 512):
+        for w in (1, 2, 4, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert sum(shard_sizes(n, w)) == n
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens
+rank, world, _ = init_distributed()
+n = int(sys.argv[2])
+lo, hi = shard_range(n, rank, world)
+full = (torch.arange(n * 3 * 5, dtype=torch.int32).view(n, 3, 5) * 7) % 1000
+out = all_gather_tokens(full[lo:hi].clone(), world, n_segments=n)
+assert torch.equal(out, full), (rank, out.shape)
+torch.distributed.barrier()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("n", [8, 7])
+def test_all_gather_world_size_2_gloo(tmp_path, n):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + n), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

@@ -9,12 +9,12 @@ import os
 from .config import CConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libymt3_hip.so")
+LIB_PATH = os.environ.get("YMT3_LIB", os.path.join(_HERE, "libymt3_hip.so"))
 
 # every symbol include/ymt3.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "ymt3_abi_version", "ymt3_last_error", "ymt3_create", "ymt3_destroy", "ymt3_device_bytes",
-    "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm",
+    "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm", "ymt3_profile_decode",
 ]
 
 _lib = None
@@ -32,6 +32,11 @@ def load() -> ctypes.CDLL:
         raise YMT3Error(
             f"{LIB_PATH} not found: build it with `python -m yourmt3_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+    # The process must hold ONE HIP runtime.  torch ships its own libamdhip64.so (SONAME libamdhip64.so.7)
+    # and device pointers / streams are shared with it, so torch has to be loaded first: our NEEDED
+    # libamdhip64.so.7 then binds to torch's copy.  Loaded the other way round the process ends up with
+    # two runtimes and the second one sees no device.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     lib.ymt3_abi_version.restype = i32
@@ -47,6 +52,8 @@ def load() -> ctypes.CDLL:
     lib.ymt3_decode_greedy.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     lib.ymt3_transcribe_segments.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.ymt3_test_gemm.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.ymt3_profile_decode.argtypes = [vp, vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32), vp]
+    lib.ymt3_profile_decode.restype = i32
     for n in ("ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm"):
         getattr(lib, n).restype = i32
     if lib.ymt3_abi_version() != 1:

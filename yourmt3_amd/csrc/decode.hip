@@ -6,12 +6,12 @@
 //
 //  dec_gemm_kernel      skinny GEMM, R = segments x channels rows (64..832) against a [N][K] bf16
 //                       weight that is streamed exactly once per 64-row tile: one workgroup per 16
-//                       output columns, the four waves split K, weight fragments go straight from
-//                       global memory to MFMA operand registers (no LDS: each element is used by one
-//                       wave), partial tiles are summed through LDS in a fixed order (bitwise
-//                       reproducible; no float atomics).  NORM modes fuse the T5 RMS norm
-//                       (TP: modeling_t5.py:50-72) of the fp32 residual rows as the prologue; the
-//                       epilogues fuse KV-cache append (TP: cache_utils.py:144-145), ReLU, residual add.
+//                       output columns, eight waves split K, all fragments go straight from global
+//                       memory to MFMA operand registers (each element is used by one wave), partial
+//                       tiles are summed through LDS in a fixed order (bitwise reproducible; no float
+//                       atomics).  NORM modes apply the T5 RMS norm (TP: modeling_t5.py:50-72) to the
+//                       fp32 residual rows while building the fragments; the epilogues fuse KV-cache
+//                       append (TP: cache_utils.py:144-145), ReLU, residual add + sum(h^2) partials.
 //  dec_attn_kernel      one (row, head) per workgroup; K/V slabs streamed HBM -> registers with 16-byte
 //                       coalesced loads, 8 in flight per lane; online softmax per lane group, merged by
 //                       shuffles and one LDS pass.  Self-attention adds the unidirectional relative
@@ -29,150 +29,186 @@ namespace {
 constexpr int DKV = 64;
 
 // ------------------------------------------------------------------------------------------------
-template <int MODE, int K>
-__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs a) {
+// 512 threads = 8 waves; one workgroup = a (16*MT rows) x 16 columns output tile over the full K, each
+// wave owning K/8 of the reduction.  MT = 1 (16 rows) for R <= 128 keeps every workgroup's operand
+// traffic small (the per-CU load path, ~64 B/clk, is what bounds these kernels, not HBM): 16 rows of A
+// plus a 16 x K weight tile; workgroups that share a weight tile are placed on one XCD (same
+// blockIdx % 8) so its re-reads hit that XCD's L2.  MT = 4 (64 rows) for the multi-channel row counts.
+// Every operand fragment goes global -> VGPR with all loads issued before the first use (one memory
+// round trip per kernel); LDS carries only the fixed-order 8-way partial-sum reduction.  The RMS
+// norm needs sum(x^2) over the FULL row, which no single wave sees: it is carried between kernels as
+// per-row partial sums `ssq[tile][row]` written by whoever last wrote the residual stream (the 32
+// column tiles of the RESID epilogue, or the embedding gather) and summed here in a fixed order.
+template <int MODE, int K, int MT>
+__global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     constexpr bool NORM = (MODE != DG_RESID);
-    constexpr int KW = K / 4;            // K slice per wave
+    constexpr int KW = K / 8;            // K slice per wave
     constexpr int KS = KW / 32;          // MFMA k-steps per wave
-    constexpr int PITCH = K + 8;         // bf16 elements per LDS row (16-byte pad)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
-    float* red = reinterpret_cast<float*>(smem);
+    constexpr int ROWS = 16 * MT;
+    __shared__ __attribute__((aligned(16))) float red[8 * ROWS * 16];
+    __shared__ float sscale[ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
-    const int kb = wave * KW;
+    // block -> (n tile, m tile): blocks with equal blockIdx % 8 (one XCD under round-robin placement;
+    // speed only) walk the m tiles of one n tile back to back
+    const int n_mt = (a.R + ROWS - 1) / ROWS, n_nt = a.N / 16;
+    int nt_idx, mt_idx;
+    if ((n_nt & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        mt_idx = slot % n_mt;
+        nt_idx = (slot / n_mt) * 8 + xcd;
+    } else {
+        mt_idx = blockIdx.x % n_mt;
+        nt_idx = blockIdx.x / n_mt;
+    }
+    const int n0 = nt_idx * 16, m0 = a.row0 + mt_idx * ROWS, m_end = a.row0 + a.R;
+    const int kb = wave * KW + g * 8;
 
-    f32x4 acc[4];
+    // epilogue ownership: thread -> (row mr, 2 columns nq)
+    const bool epi = tid < ROWS * 8;
+    const int mr = tid >> 3, nq = (tid & 7) * 2;
+    const int m = m0 + mr, n = n0 + nq;
+    const bool live = epi && m < m_end;
+    float2 hold = make_float2(0.f, 0.f);
+    if constexpr (MODE == DG_RESID) {
+        if (live) hold = *reinterpret_cast<const float2*>(a.out_f32 + (size_t)m * a.N + n);   // prefetch the RMW operand
+    }
+
+    f32x4 acc[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const bf16_t* wrow = a.W + (size_t)(n0 + li) * K + kb + g * 8;
+    const bf16_t* wrow = a.W + (size_t)(n0 + li) * K + kb;
+    bf16x8 wf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + ks * 32));
+
+    int mrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int mm = m0 + mt * 16 + li;
+        mrow[mt] = mm < m_end ? mm : m_end - 1;
+    }
 
     if constexpr (NORM) {
-        // weight fragments first: their latency hides under the norm prologue
-        bf16x8 wf[KS];
+        float4 xv[MT][KS][2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + ks * 32));
-
-        // RMS norm of rows m0 + 16*wave .. +15 into the bf16 LDS tile
-        constexpr int NV = K / 256;      // float4 per lane per row
-#pragma unroll 4
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = wave * 16 + rr, m = m0 + row;
-            float4 v[NV];
-            float ss = 0.f;
-            if (m < a.R) {
-                const float4* xr = reinterpret_cast<const float4*>(a.x_f32 + (size_t)m * K);
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    v[i] = xr[lane + 64 * i];
-                    ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4* px = reinterpret_cast<const float4*>(a.x_f32 + (size_t)mrow[mt] * K + kb + ks * 32);
+                xv[mt][ks][0] = px[0];
+                xv[mt][ks][1] = px[1];
             }
-            ss = wave_sum(ss);
-            const float sc = rsqrtf(ss / (float)K + a.eps);
+        float4 gv[KS][2];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const float4 gn = reinterpret_cast<const float4*>(a.gain)[lane + 64 * i];
-                *reinterpret_cast<uint2*>(sA + row * PITCH + (lane + 64 * i) * 4) =
-                    make_uint2(pack_bf16x2(v[i].x * sc * gn.x, v[i].y * sc * gn.y),
-                               pack_bf16x2(v[i].z * sc * gn.z, v[i].w * sc * gn.w));
+        for (int ks = 0; ks < KS; ++ks) {
+            const float4* pg = reinterpret_cast<const float4*>(a.gain + kb + ks * 32);
+            gv[ks][0] = pg[0];
+            gv[ks][1] = pg[1];
+        }
+        // row scales from the partial sums: thread (row, part) adds 4 tiles, 8 parts combine by shuffle
+        float ss = 0.f;
+        if (epi) {
+            const int mm = m < m_end ? m : m_end - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss += a.ssq[(size_t)((tid & 7) * 4 + j) * a.ssq_stride + mm];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all operand loads are in flight before anything waits
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        if (epi && (tid & 7) == 0) sscale[mr] = rsqrtf(ss / (float)K + a.eps);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float sc = sscale[mt * 16 + li];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4 x0 = xv[mt][ks][0], x1 = xv[mt][ks][1], g0 = gv[ks][0], g1 = gv[ks][1];
+                bf16x8 af;
+                af[0] = (__bf16)(x0.x * sc * g0.x); af[1] = (__bf16)(x0.y * sc * g0.y);
+                af[2] = (__bf16)(x0.z * sc * g0.z); af[3] = (__bf16)(x0.w * sc * g0.w);
+                af[4] = (__bf16)(x1.x * sc * g1.x); af[5] = (__bf16)(x1.y * sc * g1.y);
+                af[6] = (__bf16)(x1.z * sc * g1.z); af[7] = (__bf16)(x1.w * sc * g1.w);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af, acc[mt], 0, 0, 0);
             }
         }
-        __syncthreads();
+    } else {
+        bf16x8 af[MT][KS];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                af[mt][ks] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const uint4*>(a.a_bf16 + (size_t)mrow[mt] * K + kb + ks * 32));
+        __builtin_amdgcn_sched_barrier(0);   // keep every load above the first MFMA: one round trip, not KS of them
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const bf16x8 af = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const uint4*>(sA + (mt * 16 + li) * PITCH + kb + ks * 32 + g * 8));
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af, acc[mt], 0, 0, 0);
-            }
-        __syncthreads();                 // sA is dead; `red` aliases it
-    } else {
-        // A is bf16 in global memory and each element feeds exactly one wave: no LDS staging
-        const bf16_t* arow[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            int m = m0 + mt * 16 + li;
-            m = m < a.R ? m : a.R - 1;
-            arow[mt] = a.a_bf16 + (size_t)m * K + kb + g * 8;
-        }
-        constexpr int U = KS < 4 ? KS : 4;
-#pragma unroll 1
-        for (int k0 = 0; k0 < KS; k0 += U) {
-            bf16x8 wf[U], af[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                wf[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + (k0 + u) * 32));
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    af[u][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow[mt] + (k0 + u) * 32));
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[u][mt], acc[mt], 0, 0, 0);
-        }
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[mt][ks], acc[mt], 0, 0, 0);
     }
 
-    // fixed-order cross-wave reduction: red[wave][m (64)][n (16)]
+    // fixed-order cross-wave reduction: red[wave][row][n (16)]
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-        *reinterpret_cast<float4*>(red + ((wave * 64 + mt * 16 + li) * 16 + g * 4)) =
+    for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<float4*>(red + ((wave * ROWS + mt * 16 + li) * 16 + g * 4)) =
             make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
     __syncthreads();
-    const int mr = tid >> 2, nq = (tid & 3) * 4;
-    float4 s = *reinterpret_cast<const float4*>(red + (mr * 16 + nq));
+    float2 s = make_float2(0.f, 0.f);
+    if (epi) {
+        s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        const float4 t = *reinterpret_cast<const float4*>(red + ((w * 64 + mr) * 16 + nq));
-        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        for (int w = 1; w < 8; ++w) {
+            const float2 t = *reinterpret_cast<const float2*>(red + ((w * ROWS + mr) * 16 + nq));
+            s.x += t.x; s.y += t.y;
+        }
     }
-    const int m = m0 + mr, n = n0 + nq;
-    if (m >= a.R) return;
 
     if constexpr (MODE == DG_RESID) {
-        float4* p = reinterpret_cast<float4*>(a.out_f32 + (size_t)m * a.N + n);
-        float4 o = *p;
-        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
-        *p = o;
-    } else if constexpr (MODE == DG_NORM_LOGITS) {
-        *reinterpret_cast<float4*>(a.out_f32 + (size_t)m * a.N + n) = s;
-    } else {
-        if constexpr (MODE == DG_NORM_BF16_RELU) {
-            s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+        float2 o = make_float2(0.f, 0.f);
+        if (live) {
+            o = make_float2(hold.x + s.x, hold.y + s.y);
+            *reinterpret_cast<float2*>(a.out_f32 + (size_t)m * a.N + n) = o;
         }
-        const uint2 pk = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+        // this tile's share of sum(h^2) for the next norm
+        float q = o.x * o.x + o.y * o.y;
+        q += __shfl_xor(q, 1, 64);
+        q += __shfl_xor(q, 2, 64);
+        q += __shfl_xor(q, 4, 64);
+        if (live && (tid & 7) == 0) a.ssq[(size_t)nt_idx * a.ssq_stride + m] = q;
+    } else if constexpr (MODE == DG_NORM_LOGITS) {
+        if (live) *reinterpret_cast<float2*>(a.out_f32 + (size_t)m * a.N + n) = s;
+    } else {
+        if (!live) return;
+        if constexpr (MODE == DG_NORM_BF16_RELU) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); }
+        const uint32_t pk = pack_bf16x2(s.x, s.y);
         if constexpr (MODE == DG_NORM_QKV_CACHE) {
             const int inner = a.H * DKV;
             if (n < inner) {
-                *reinterpret_cast<uint2*>(a.out_bf16 + (size_t)m * inner + n) = pk;
+                *reinterpret_cast<uint32_t*>(a.out_bf16 + (size_t)m * inner + n) = pk;
             } else {
                 const int step = a.shared->step;
                 const int nn = n - inner, kv = nn / inner, hh = (nn % inner) >> 6, dd = nn & 63;
                 bf16_t* cache = kv ? a.vcache : a.kcache;
-                *reinterpret_cast<uint2*>(cache + (((size_t)m * a.H + hh) * a.L + step) * DKV + dd) = pk;
+                *reinterpret_cast<uint32_t*>(cache + (((size_t)m * a.H + hh) * a.L + step) * DKV + dd) = pk;
             }
         } else {
-            *reinterpret_cast<uint2*>(a.out_bf16 + (size_t)m * a.N + n) = pk;
+            *reinterpret_cast<uint32_t*>(a.out_bf16 + (size_t)m * a.N + n) = pk;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 template <bool SELF>
-__global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
-    __shared__ float sm[4], sl[4], sacc[4][DKV];
+__global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
+    constexpr int NW = 8;                       // waves per (row, head): 16 waves / CU keep > 12 MB in flight chip-wide
+    __shared__ float sm[NW], sl[NW], sacc[NW][DKV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 7, kg = lane >> 3;
-    const int r = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int r = a.row0 + blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int n_keys = SELF ? a.shared->step + 1 : a.n_keys_const;
     const int kv_row = r / a.rows_per_kv;
     const size_t slab = ((size_t)kv_row * a.H + h) * a.slab_keys * DKV;
@@ -180,39 +216,51 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
     const bf16_t* vb = a.v + slab + sub * 8;
     const float* bias = SELF ? a.bias + (size_t)h * a.bias_stride : nullptr;
 
-    float qf[8];
-    unpack8(*reinterpret_cast<const uint4*>(a.q + ((size_t)r * a.H + h) * DKV + sub * 8), qf);
+    // q stays packed (4 x bf16x2); halves are widened to fp32 at use
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 qp = *reinterpret_cast<const u32x4*>(a.q + ((size_t)r * a.H + h) * DKV + sub * 8);
 
     float m = -1.0e30f, l = 0.f, acc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.f;
 
-    constexpr int U = 4;
-    for (int kw = wave * 8; kw < n_keys; kw += 32 * U) {     // wave-uniform trip count
+    // The self-attention cache (up to 805 MB) is read exactly once per step: non-temporal loads keep it
+    // from evicting the weights (42 MB) and the cross-attention K/V (201 MB at 64 segments), both
+    // re-read every step, out of the 256 MB Infinity Cache.  16 x 16-byte loads in flight per lane.
+    constexpr int U = SELF ? 8 : 4;            // cross: 8 waves x 8 keys x 4 = 256 frames in one shot
+    for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {     // wave-uniform trip count
         const int k0 = kw + kg;
-        uint4 ku[U], vu[U];
+        u32x4 ku[U], vu[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = k0 + 32 * u;
+            const int key = k0 + 8 * NW * u;
             ok[u] = key < n_keys;
             const int kc = ok[u] ? key : 0;
-            ku[u] = *reinterpret_cast<const uint4*>(kb + (size_t)kc * DKV);
-            vu[u] = *reinterpret_cast<const uint4*>(vb + (size_t)kc * DKV);
+            if constexpr (SELF) {
+                ku[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV));
+                vu[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV));
+            } else {
+                ku[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV);
+                vu[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV);
+            }
         }
         float sc[U];
         float mn = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float kf[8];
-            unpack8(ku[u], kf);
             float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) s = fmaf(qf[d], kf[d], s);
+            // plain fp32 FMAs on the unpacked halves: v_dot2c_f32_bf16 chains gave O(1) wrong scores on
+            // gfx950 / ROCm 7.2 in this kernel (bisected on hardware), so the packed dot is not used
+            for (int j = 0; j < 4; ++j) {
+                s = fmaf(__uint_as_float(qp[j] << 16), __uint_as_float(ku[u][j] << 16), s);
+                s = fmaf(__uint_as_float(qp[j] & 0xffff0000u), __uint_as_float(ku[u][j] & 0xffff0000u), s);
+            }
             s += __shfl_xor(s, 1, 64);
             s += __shfl_xor(s, 2, 64);
             s += __shfl_xor(s, 4, 64);
-            if (SELF && ok[u]) s += bias[n_keys - 1 - (k0 + 32 * u)];
+            if (SELF && ok[u]) s += bias[n_keys - 1 - (k0 + 8 * NW * u)];
             sc[u] = s;
             if (ok[u]) mn = fmaxf(mn, s);
         }
@@ -223,11 +271,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float p = ok[u] ? __expf(sc[u] - mn) : 0.f;
-            float vf[8];
-            unpack8(vu[u], vf);
             l += p;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) acc[d] = fmaf(p, vf[d], acc[d]);
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] = fmaf(p, __uint_as_float(vu[u][j] << 16), acc[2 * j]);
+                acc[2 * j + 1] = fmaf(p, __uint_as_float(vu[u][j] & 0xffff0000u), acc[2 * j + 1]);
+            }
         }
         m = mn;
     }
@@ -249,10 +298,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
     }
     __syncthreads();
     if (tid < DKV) {
-        const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        float M = sm[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) M = fmaxf(M, sm[w]);
         float L = 0.f, o = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float e = __expf(sm[w] - M);
             L += sl[w] * e;
             o += sacc[w][tid] * e;
@@ -262,12 +313,28 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// h[r] = embed row (+ channel row); sum(h^2) goes to ssq tile 0 of the row, tiles 1.. are zeroed
+__device__ __forceinline__ void embed_row(const ArgmaxArgs& a, int r, const bf16_t* e, const bf16_t* c, float* scratch4) {
+    const int tid = threadIdx.x;
+    float q = 0.f;
+    for (int i = tid; i < a.d; i += 256) {
+        const float v = bf2f(e[i]) + (c ? bf2f(c[i]) : 0.f);
+        a.h[(size_t)r * a.d + i] = v;
+        q += v * v;
+    }
+    q = wave_sum(q);
+    __syncthreads();                       // scratch4 may still be read by the caller's previous phase
+    if ((tid & 63) == 0) scratch4[tid >> 6] = q;
+    __syncthreads();
+    if (tid < SSQ_TILES) a.ssq[(size_t)tid * a.ssq_stride + r] = tid == 0 ? (scratch4[0] + scratch4[1]) + (scratch4[2] + scratch4[3]) : 0.f;
+}
+
 __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     __shared__ float sv[4];
     __shared__ int si[4];
     __shared__ int s_feed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = blockIdx.x;
+    const int r = a.row0 + blockIdx.x;
     DecodeShared* sh = a.shared;
     const int t = sh->step, n_steps = sh->n_steps;
     const float* row = a.logits + (size_t)r * a.V;
@@ -302,7 +369,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     const int feed = s_feed;
     const bf16_t* e = a.embed + (size_t)feed * a.d;
     const bf16_t* c = a.chan_embed ? a.chan_embed + (size_t)(r % a.n_channels) * a.d : nullptr;
-    for (int i = tid; i < a.d; i += 256) a.h[(size_t)r * a.d + i] = bf2f(e[i]) + (c ? bf2f(c[i]) : 0.f);
+    embed_row(a, r, e, c, sv);
     if (sh->logits_out) {
         float* dst = sh->logits_out + ((size_t)r * n_steps + t) * a.V;
         for (int i = tid; i < a.V; i += 256) dst[i] = row[i];
@@ -319,50 +386,41 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_steps, int32_t* tokens_out,
+__global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_chains, int n_steps, int32_t* tokens_out,
                                                           const int32_t* forced, float* logits_out) {
     const int r = blockIdx.x, tid = threadIdx.x;
     const bf16_t* e = a.embed + (size_t)a.pad_id * a.d;
     const bf16_t* c = a.chan_embed ? a.chan_embed + (size_t)(r % a.n_channels) * a.d : nullptr;
-    for (int i = tid; i < a.d; i += 256) a.h[(size_t)r * a.d + i] = bf2f(e[i]) + (c ? bf2f(c[i]) : 0.f);
+    __shared__ float sv[4];
+    embed_row(a, r, e, c, sv);
     if (tid == 0) a.finished[r] = 0;
-    if (r == 0 && tid == 0) {
-        a.shared->step = 0;
-        a.shared->done_count = 0;
-        a.shared->n_steps = n_steps;
-        a.shared->tokens_out = tokens_out;
-        a.shared->forced = forced;
-        a.shared->logits_out = logits_out;
+    if (r == 0 && tid < n_chains) {          // a.shared is the array of per-chain loop states
+        DecodeShared* sh = a.shared + tid;
+        sh->step = 0;
+        sh->done_count = 0;
+        sh->n_steps = n_steps;
+        sh->tokens_out = tokens_out;
+        sh->forced = forced;
+        sh->logits_out = logits_out;
     }
 }
 
 template <int MODE, int K>
 int launch_dg(const DecGemmArgs& a, hipStream_t stream) {
-    constexpr size_t lds_norm = (size_t)64 * (K + 8) * 2;
-    constexpr size_t lds_red = 4 * 64 * 16 * 4;
-    constexpr size_t lds = (MODE != DG_RESID) ? (lds_norm > lds_red ? lds_norm : lds_red) : lds_red;
-    if (a.W == nullptr) {   // attribute-only call from init_decode_kernels()
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -2;
+    if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;   // the norm consumers sum exactly SSQ_TILES partials
+    if (a.R <= 128) {
+        const int n_mt = (a.R + 15) / 16;
+        dec_gemm_kernel<MODE, K, 1><<<(a.N / 16) * n_mt, 512, 0, stream>>>(a);
+    } else {
+        const int n_mt = (a.R + 63) / 64;
+        dec_gemm_kernel<MODE, K, 4><<<(a.N / 16) * n_mt, 512, 0, stream>>>(a);
     }
-    dec_gemm_kernel<MODE, K><<<dim3(a.N / 16, (a.R + 63) / 64), 256, lds, stream>>>(a);
     return 0;
 }
 
 }  // namespace
 
-int init_decode_kernels() {
-    DecGemmArgs z{};
-    int rc = 0;
-    rc |= launch_dg<DG_RESID, 512>(z, nullptr);
-    rc |= launch_dg<DG_RESID, 1024>(z, nullptr);
-    rc |= launch_dg<DG_RESID, 2048>(z, nullptr);
-    rc |= launch_dg<DG_NORM_QKV_CACHE, 512>(z, nullptr);
-    rc |= launch_dg<DG_NORM_BF16, 512>(z, nullptr);
-    rc |= launch_dg<DG_NORM_BF16_RELU, 512>(z, nullptr);
-    rc |= launch_dg<DG_NORM_LOGITS, 512>(z, nullptr);
-    return rc;
-}
+int init_decode_kernels() { return 0; }
 
 int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
@@ -385,8 +443,8 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
 
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
-    if (self_attn) dec_attn_kernel<true><<<a.R * a.H, 256, 0, stream>>>(a);
-    else dec_attn_kernel<false><<<a.R * a.H, 256, 0, stream>>>(a);
+    if (self_attn) dec_attn_kernel<true><<<a.R * a.H, 512, 0, stream>>>(a);
+    else dec_attn_kernel<false><<<a.R * a.H, 512, 0, stream>>>(a);
     return 0;
 }
 
@@ -396,9 +454,9 @@ int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream) {
     return 0;
 }
 
-int launch_decode_init(const ArgmaxArgs& a, int n_steps, int32_t* tokens_out, const int32_t* forced, float* logits_out,
-                       hipStream_t stream) {
+int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int32_t* tokens_out, const int32_t* forced,
+                       float* logits_out, hipStream_t stream) {
     if (a.R <= 0) return 0;
-    decode_init_kernel<<<a.R, 256, 0, stream>>>(a, n_steps, tokens_out, forced, logits_out);
+    decode_init_kernel<<<a.R, 256, 0, stream>>>(a, n_chains, n_steps, tokens_out, forced, logits_out);
     return 0;
 }

@@ -55,12 +55,14 @@ struct DecodeShared {           // device-resident loop state, read by every dec
     float* logits_out;          // [R][n_steps][V] or null
 };
 
+constexpr int SSQ_TILES = 32;    // sum(h^2) partials per row = d_model / 16 column tiles of the RESID epilogue
+
 struct DecGemmArgs {
     const float* x_f32;         // NORM variants: residual stream [R][K] fp32
     const float* gain;          // NORM variants: [K]
     const bf16_t* a_bf16;       // plain variants: [R][K] bf16
     const bf16_t* W;            // [N][K] bf16
-    int R, N, K;
+    int row0, R, N, K;          // rows [row0, row0 + R) of every row-indexed buffer
     float eps;
     // outputs (by mode)
     bf16_t* out_bf16;           // [R][N] (MODE_BF16, MODE_BF16_RELU, q part of MODE_QKV_CACHE)
@@ -69,6 +71,8 @@ struct DecGemmArgs {
     bf16_t* vcache;
     int H, L;                   // cache geometry
     const DecodeShared* shared; // MODE_QKV_CACHE reads shared->step
+    float* ssq;                 // [SSQ_TILES][ssq_stride] per-row partial sums of h^2 (read by NORM, written by RESID)
+    int ssq_stride;
 };
 enum DecGemmMode { DG_NORM_QKV_CACHE = 0, DG_NORM_BF16 = 1, DG_NORM_BF16_RELU = 2, DG_NORM_LOGITS = 3, DG_RESID = 4 };
 int init_decode_kernels();
@@ -84,7 +88,7 @@ struct DecAttnArgs {
     int n_keys_const;           // cross: fixed key count
     int slab_keys;              // keys allocated per (row, head) slab (L for self, T for cross)
     int rows_per_kv;            // 1 for self; n_channels for cross (row r reads segment r / n_channels)
-    int R, H, bias_stride;
+    int row0, R, H, bias_stride;
 };
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream);
 
@@ -95,9 +99,11 @@ struct ArgmaxArgs {
     const bf16_t* chan_embed;   // [K][d] or null
     DecodeShared* shared;
     int* finished;              // [R]
-    int R, V, d, n_channels, eos_id, pad_id;
+    float* ssq;                 // [SSQ_TILES][ssq_stride]
+    int ssq_stride;
+    int row0, R, V, d, n_channels, eos_id, pad_id;
 };
 int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream);
-// h[r] = embed[pad] (+ chan_embed), finished = 0, shared fields reset
-int launch_decode_init(const ArgmaxArgs& a, int n_steps, int32_t* tokens_out, const int32_t* forced, float* logits_out,
-                       hipStream_t stream);
+// all rows: h[r] = embed[pad] (+ chan_embed), finished = 0; a.shared[0..n_chains) reset
+int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int32_t* tokens_out, const int32_t* forced,
+                       float* logits_out, hipStream_t stream);

@@ -69,12 +69,39 @@ struct ymt3_ctx {
     float* h_dec = nullptr;
     bf16_t *dq = nullptr, *dattn = nullptr, *dff = nullptr;
     float* logits = nullptr;
+    float* ssq = nullptr;               // [SSQ_TILES][maxR]
     int* finished = nullptr;
-    DecodeShared* shared = nullptr;
+    DecodeShared* shared = nullptr;     // [MAX_CHAINS] per-chain loop state
     hipStream_t cap_stream = nullptr;
-    std::map<int, StepGraph> step_graphs;   // keyed by B
+    // Decode rows are independent, so a batch CAN be cut into `n_chains` contiguous row ranges whose
+    // step graphs replay concurrently on separate HIP streams.  Measured on MI355X (profiles/r01_notes.md):
+    // it loses -- every hipGraphLaunch of the ~50-node step costs ~150 us of host time, so 2/4/8 chains
+    // ran 372/653/937 ms per batch against 351 ms for one chain.  Default 1; YMT3_CHAINS overrides.
+    int n_chains = 1;
+    hipStream_t chain_stream[8] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[8] = {};
+    std::map<long, StepGraph> step_graphs;  // keyed by (B, n_chains_used, chain)
     bool use_graph = true;
+    // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;        // pairs
+    std::vector<int> prof_cls;
 };
+
+enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_COUNT };
+
+struct ProfScope {
+    ymt3_ctx* c; hipStream_t s; bool on;
+    ProfScope(ymt3_ctx* c_, int cls, hipStream_t s_) : c(c_), s(s_), on(c_->prof_on) {
+        if (!on) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        c->prof_ev.push_back(a); c->prof_ev.push_back(b); c->prof_cls.push_back(cls);
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(c->prof_ev.back(), s); }
+};
+#define PLAUNCH(cls, expr) do { ProfScope _ps(h, cls, s); LAUNCH(expr); } while (0)
 
 static int dev_alloc(ymt3_ctx* c, void** p, size_t bytes) {
     HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
@@ -150,6 +177,11 @@ extern "C" void ymt3_destroy(ymt3_handle h) {
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    for (int i = 0; i < 8; ++i) {
+        if (h->chain_stream[i]) (void)hipStreamDestroy(h->chain_stream[i]);
+        if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
+    }
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -159,7 +191,7 @@ extern "C" size_t ymt3_device_bytes(ymt3_handle h) { return h ? h->dev_bytes : 0
 static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, size_t nbytes) {
     const ymt3_config& k = c->cfg;
     if (k.d_kv != 64) FAIL(YMT3_ERR_UNSUPPORTED, "d_kv must be 64 (got %d)", k.d_kv);
-    if (k.d_model != 512) FAIL(YMT3_ERR_UNSUPPORTED, "d_model must be 512 (got %d)", k.d_model);
+    if (k.d_model != 16 * SSQ_TILES) FAIL(YMT3_ERR_UNSUPPORTED, "d_model must be 512 (got %d)", k.d_model);
     if (k.n_heads * k.d_kv != 512) FAIL(YMT3_ERR_UNSUPPORTED, "n_heads*d_kv must be 512");
     if (k.encoder_type != YMT3_ENC_T5) FAIL(YMT3_ERR_UNSUPPORTED, "encoder_type %d not built yet", k.encoder_type);
     if (k.dec_ffn != YMT3_FFN_DENSE) FAIL(YMT3_ERR_UNSUPPORTED, "dec_ffn %d not built yet", k.dec_ffn);
@@ -219,11 +251,19 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->dff, R * k.d_ff * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->logits, R * k.vocab * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->finished, R * 4)) return YMT3_ERR_HIP;
-    if (dev_alloc(c, (void**)&c->shared, sizeof(DecodeShared))) return YMT3_ERR_HIP;
-    HIP_TRY(hipMemset(c->shared, 0, sizeof(DecodeShared)));
+    if (dev_alloc(c, (void**)&c->ssq, (size_t)SSQ_TILES * R * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->shared, 8 * sizeof(DecodeShared))) return YMT3_ERR_HIP;
+    HIP_TRY(hipMemset(c->shared, 0, 8 * sizeof(DecodeShared)));
     HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     const char* ng = getenv("YMT3_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
+    const char* nc = getenv("YMT3_CHAINS");
+    if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
+    for (int i = 0; i < c->n_chains; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->chain_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
 
     // every tensor the kernels will ask for must be present now, not at the first call
     const char* enc_names[] = {"ln1", "wqkv", "wo", "ln2", "wi", "wo2"};
@@ -318,10 +358,11 @@ extern "C" int ymt3_encode(ymt3_handle h, const float* mel_dev, int B, void* enc
     return encode_impl(h, mel_dev, B, static_cast<bf16_t*>(enc_dev), (hipStream_t)stream);
 }
 
-// one decoder step = 8 kernels per layer + lm_head + argmax, all reading the position from h->shared
-static int launch_step(ymt3_handle h, int B, hipStream_t s) {
+// one decoder step of rows [row0, row0 + R) = 8 kernels per layer + lm_head + argmax, all reading the
+// position from the chain's DecodeShared
+static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shared, hipStream_t s) {
     const ymt3_config& k = h->cfg;
-    const int R = B * k.n_channels, d = k.d_model, inner = h->inner, H = k.n_heads, L = k.max_decode_len;
+    const int d = k.d_model, inner = h->inner, H = k.n_heads, L = k.max_decode_len;
     const size_t layer_cache = (size_t)h->maxR * H * L * 64;
     const size_t slab = (size_t)B * H * h->T * 64;
     const float* bias_dist;
@@ -331,57 +372,57 @@ static int launch_step(ymt3_handle h, int B, hipStream_t s) {
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const std::string p = "dec." + std::to_string(l) + ".";
         DecGemmArgs a{};
-        a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = h->shared;
+        a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
         // self-attention block
         GET(h, p + "ln1", 0u, &f, (size_t)d);
         GET(h, p + "wqkv", 1u, &w, (size_t)3 * inner * d);
         a.x_f32 = h->h_dec; a.gain = f; a.W = w; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
         a.kcache = h->kcache + l * layer_cache; a.vcache = h->vcache + l * layer_cache;
-        LAUNCH(launch_dec_gemm(DG_NORM_QKV_CACHE, a, s));
+        PLAUNCH(PC_QKV, launch_dec_gemm(DG_NORM_QKV_CACHE, a, s));
         DecAttnArgs t{};
-        t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = h->shared;
+        t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
         t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
-        LAUNCH(launch_dec_attention(true, t, s));
+        PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
         GET(h, p + "wo", 1u, &w, (size_t)d * inner);
         a.a_bf16 = h->dattn; a.W = w; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
-        LAUNCH(launch_dec_gemm(DG_RESID, a, s));
+        PLAUNCH(PC_SELF_O, launch_dec_gemm(DG_RESID, a, s));
         // cross-attention block
         GET(h, p + "ln2", 0u, &f, (size_t)d);
         GET(h, p + "wq_c", 1u, &w, (size_t)inner * d);
         a.gain = f; a.W = w; a.N = inner; a.K = d; a.out_bf16 = h->dq;
-        LAUNCH(launch_dec_gemm(DG_NORM_BF16, a, s));
+        PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
         t.k = h->ckv + (size_t)(2 * l) * slab; t.v = h->ckv + (size_t)(2 * l + 1) * slab; t.bias = nullptr;
         t.n_keys_const = h->T; t.slab_keys = h->T; t.rows_per_kv = k.n_channels;
-        LAUNCH(launch_dec_attention(false, t, s));
+        PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
         GET(h, p + "wo_c", 1u, &w, (size_t)d * inner);
         a.a_bf16 = h->dattn; a.W = w; a.N = d; a.K = inner;
-        LAUNCH(launch_dec_gemm(DG_RESID, a, s));
+        PLAUNCH(PC_CROSS_O, launch_dec_gemm(DG_RESID, a, s));
         // feed-forward block
         GET(h, p + "ln3", 0u, &f, (size_t)d);
         GET(h, p + "wi", 1u, &w, (size_t)k.d_ff * d);
         a.gain = f; a.W = w; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
-        LAUNCH(launch_dec_gemm(DG_NORM_BF16_RELU, a, s));
+        PLAUNCH(PC_FFN_WI, launch_dec_gemm(DG_NORM_BF16_RELU, a, s));
         GET(h, p + "wo2", 1u, &w, (size_t)d * k.d_ff);
         a.a_bf16 = h->dff; a.W = w; a.N = d; a.K = k.d_ff;
-        LAUNCH(launch_dec_gemm(DG_RESID, a, s));
+        PLAUNCH(PC_FFN_WO, launch_dec_gemm(DG_RESID, a, s));
     }
     DecGemmArgs a{};
-    a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = h->shared;
+    a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
     GET(h, "dec.ln_f", 0u, &f, (size_t)d);
     GET(h, "dec.lm_head", 1u, &w, (size_t)k.vocab * d);
     a.x_f32 = h->h_dec; a.gain = f; a.W = w; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
-    LAUNCH(launch_dec_gemm(DG_NORM_LOGITS, a, s));
+    PLAUNCH(PC_LM_HEAD, launch_dec_gemm(DG_NORM_LOGITS, a, s));
     ArgmaxArgs g{};
-    g.logits = h->logits; g.h = h->h_dec; g.shared = h->shared; g.finished = h->finished;
+    g.logits = h->logits; g.h = h->h_dec; g.shared = shared; g.finished = h->finished; g.ssq = h->ssq; g.ssq_stride = h->maxR; g.row0 = row0;
     g.R = R; g.V = k.vocab; g.d = d; g.n_channels = k.n_channels; g.eos_id = k.eos_id; g.pad_id = k.pad_id;
     GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&g.embed), (size_t)k.vocab * d);
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&g.chan_embed), (size_t)k.n_channels * d);
-    LAUNCH(launch_argmax_embed(g, s));
+    PLAUNCH(PC_ARGMAX, launch_argmax_embed(g, s));
     return YMT3_OK;
 }
 
 static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int32_t* tokens, const int32_t* forced,
-                       float* logits_out, hipStream_t s) {
+                       float* logits_out, hipStream_t s, int prof_stride = 0) {
     const ymt3_config& k = h->cfg;
     if (n_steps <= 0 || n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len);
     const int d = k.d_model, R = B * k.n_channels;
@@ -390,28 +431,53 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
     LAUNCH(launch_gemm(EPI_KV_HEADMAJOR, g, s));
 
     ArgmaxArgs a{};
-    a.h = h->h_dec; a.shared = h->shared; a.finished = h->finished;
+    a.h = h->h_dec; a.shared = h->shared; a.finished = h->finished; a.ssq = h->ssq; a.ssq_stride = h->maxR;
     a.R = R; a.V = k.vocab; a.d = d; a.n_channels = k.n_channels; a.eos_id = k.eos_id; a.pad_id = k.pad_id;
     GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&a.embed), (size_t)k.vocab * d);
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&a.chan_embed), (size_t)k.n_channels * d);
-    LAUNCH(launch_decode_init(a, n_steps, tokens, forced, logits_out, s));
+    // chains: contiguous, near-equal row ranges
+    int n_chains = (!h->use_graph || prof_stride > 0) ? 1 : h->n_chains;
+    if (n_chains > R) n_chains = R;
+    LAUNCH(launch_decode_init(a, n_chains, n_steps, tokens, forced, logits_out, s));
+    int row0[9];
+    row0[0] = 0;
+    for (int c = 0; c < n_chains; ++c) row0[c + 1] = row0[c] + R / n_chains + (c < R % n_chains ? 1 : 0);
 
-    if (!h->use_graph) {
+    if (!h->use_graph || prof_stride > 0) {
         for (int t = 0; t < n_steps; ++t) {
-            int rc = launch_step(h, B, s);
+            h->prof_on = prof_stride > 0 && (t % prof_stride) == 0;
+            int rc = launch_step(h, B, 0, R, h->shared, s);
+            h->prof_on = false;
             if (rc) return rc;
         }
     } else {
-        StepGraph& sg = h->step_graphs[B];
-        if (!sg.exec) {
-            HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = launch_step(h, B, h->cap_stream);
-            hipError_t e = hipStreamEndCapture(h->cap_stream, &sg.graph);
-            if (rc) return rc;
-            if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            HIP_TRY(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+        hipGraphExec_t exec[8];
+        for (int c = 0; c < n_chains; ++c) {
+            StepGraph& sg = h->step_graphs[((long)B * 16 + n_chains) * 16 + c];
+            if (!sg.exec) {
+                HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+                int rc = launch_step(h, B, row0[c], row0[c + 1] - row0[c], h->shared + c, h->cap_stream);
+                hipError_t e = hipStreamEndCapture(h->cap_stream, &sg.graph);
+                if (rc) return rc;
+                if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+                HIP_TRY(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+            }
+            exec[c] = sg.exec;
         }
-        for (int t = 0; t < n_steps; ++t) HIP_TRY(hipGraphLaunch(sg.exec, s));
+        if (n_chains == 1) {
+            for (int t = 0; t < n_steps; ++t) HIP_TRY(hipGraphLaunch(exec[0], s));
+        } else {
+            // fork: every chain stream waits for the cross-KV GEMM + init on the caller's stream
+            HIP_TRY(hipEventRecord(h->fork_ev, s));
+            for (int c = 0; c < n_chains; ++c) HIP_TRY(hipStreamWaitEvent(h->chain_stream[c], h->fork_ev, 0));
+            for (int t = 0; t < n_steps; ++t)
+                for (int c = 0; c < n_chains; ++c) HIP_TRY(hipGraphLaunch(exec[c], h->chain_stream[c]));
+            // join: the caller's stream continues only after every chain has emitted its last token
+            for (int c = 0; c < n_chains; ++c) {
+                HIP_TRY(hipEventRecord(h->join_ev[c], h->chain_stream[c]));
+                HIP_TRY(hipStreamWaitEvent(s, h->join_ev[c], 0));
+            }
+        }
     }
     HIP_TRY(hipGetLastError());
     return YMT3_OK;
@@ -447,3 +513,31 @@ extern "C" int ymt3_test_gemm(ymt3_handle h, const void* a_dev, const void* w_de
     HIP_TRY(hipGetLastError());
     return YMT3_OK;
 }
+
+extern "C" int ymt3_profile_decode(ymt3_handle h, const void* enc_dev, int B, int n_steps, int stride, int32_t* tokens_dev,
+                                   float* ms_by_class, int32_t* launches_by_class, void* stream) {
+    int rc = check_call(h, B);
+    if (rc) return rc;
+    if (!enc_dev || !tokens_dev || !ms_by_class || !launches_by_class || stride <= 0 || B == 0) FAIL(YMT3_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    h->prof_ev.clear();
+    h->prof_cls.clear();
+    rc = decode_impl(h, static_cast<const bf16_t*>(enc_dev), B, n_steps, tokens_dev, nullptr, nullptr, s, stride);
+    hipError_t e = hipStreamSynchronize(s);
+    for (int i = 0; i < YMT3_PROFILE_CLASSES; ++i) { ms_by_class[i] = 0.f; launches_by_class[i] = 0; }
+    for (size_t i = 0; i < h->prof_cls.size(); ++i) {
+        float ms = 0.f;
+        if (rc == 0 && e == hipSuccess && hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) == hipSuccess) {
+            ms_by_class[h->prof_cls[i]] += ms;
+            launches_by_class[h->prof_cls[i]] += 1;
+        }
+        (void)hipEventDestroy(h->prof_ev[2 * i]);
+        (void)hipEventDestroy(h->prof_ev[2 * i + 1]);
+    }
+    h->prof_ev.clear();
+    h->prof_cls.clear();
+    if (rc) return rc;
+    if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    return YMT3_OK;
+}
+static_assert(PC_COUNT <= YMT3_PROFILE_CLASSES, "profile class table");

@@ -1,0 +1,63 @@
+"""Data-parallel sharding of segment batches: one process per GPU, segments are
+independent units, the only collective is an all-gather of int32 token ids (<= ~0.5 MB per rank, so
+latency-bound: one single-shot all-gather per batch, RCCL over xGMI; `nccl` IS RCCL on ROCm).
+Works on CPU with gloo for the world_size-2 tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(n_gpus_hint: int = 1) -> Tuple[int, int, int]:
+    """Read RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run) and join the process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def shard_range(n_segments: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block split: rank r owns [r*ceil(n/W), min((r+1)*ceil(n/W), n))."""
+    per = -(-n_segments // world)
+    lo = min(rank * per, n_segments)
+    return lo, min(lo + per, n_segments)
+
+
+def shard_sizes(n_segments: int, world: int) -> List[int]:
+    return [shard_range(n_segments, r, world)[1] - shard_range(n_segments, r, world)[0] for r in range(world)]
+
+
+def all_gather_tokens(tokens: torch.Tensor, world: int, n_segments: int | None = None) -> torch.Tensor:
+    """(b_local, K, L) int32 per rank -> (n_segments, K, L) on every rank, in segment order.
+
+    Equal shards use one all_gather_into_tensor.  Ragged shards (the tail rank has fewer segments)
+    are padded to the largest shard, gathered, and the padding rows dropped.
+    """
+    if world == 1:
+        return tokens
+    b, K, L = tokens.shape
+    if n_segments is None:
+        n_segments = b * world
+    sizes = shard_sizes(n_segments, world)
+    bmax = max(sizes)
+    if b < bmax:
+        pad = torch.zeros(bmax - b, K, L, dtype=tokens.dtype, device=tokens.device)
+        tokens = torch.cat([tokens, pad], 0)
+    out = torch.empty(world * bmax, K, L, dtype=tokens.dtype, device=tokens.device)
+    dist.all_gather_into_tensor(out, tokens.contiguous())
+    if all(s == bmax for s in sizes):
+        return out
+    return torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], 0)

@@ -115,6 +115,19 @@ class YourMT3:
             out.append(self.inference(audio_segments[i:i + bsz], max_token_length=max_token_length).cpu().numpy())
         return out
 
+    PROFILE_CLASSES = ["qkv_cache_gemm", "self_attn", "self_o_gemm", "cross_q_gemm", "cross_attn", "cross_o_gemm",
+                       "ffn_wi_gemm", "ffn_wo_gemm", "lm_head_gemm", "argmax_embed"]
+
+    def profile_decode(self, enc: torch.Tensor, n_steps: int, stride: int = 16) -> Dict[str, dict]:
+        """Eager decode with HIP events around each kernel of every `stride`-th step (include/ymt3.h)."""
+        enc = enc.to(self.device, torch.bfloat16).contiguous()
+        B = enc.shape[0]
+        tokens = torch.empty(B, self.cfg.n_channels, n_steps, device=self.device, dtype=torch.int32)
+        ms = (ctypes.c_float * 16)()
+        cnt = (ctypes.c_int32 * 16)()
+        _lib.check(self._lib.ymt3_profile_decode(self._handle, _ptr(enc), B, n_steps, stride, _ptr(tokens), ms, cnt, self._stream()))
+        return {n: {"ms_total": float(ms[i]), "launches": int(cnt[i])} for i, n in enumerate(self.PROFILE_CLASSES)}
+
     def test_gemm(self, a_bf16: torch.Tensor, w_bf16: torch.Tensor) -> torch.Tensor:
         M, K = a_bf16.shape
         N = w_bf16.shape[0]
