@@ -47,6 +47,16 @@ def self_attn_algorithmic_bytes(cfg, rows: int, t: int) -> int:
     return rows * cfg.n_heads * (t + 1) * cfg.d_kv * 2 * 2
 
 
+def pmc_traffic(cfg, B: int, L: int):
+    """HBM bytes per self-attention launch from the committed rocprofv3 PMC passes (profiles/, produced by
+    scripts/gpu_pmc.sh; FETCH_SIZE doubled per the gfx950 correction).  None if the profile does not match."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_decode_attn.json")
+    if not os.path.exists(path) or B != 64 or L != 1024 or cfg.n_channels != 1:
+        return None
+    with open(path) as f:
+        return json.load(f)["self_attn"]["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(cfg, sample_segments: int, sample_steps: int):
     """The oracle (a CPU *port* of this path, there being no reference implementation) on host cores."""
     from oracle import ymt3_oracle as O
@@ -146,7 +156,7 @@ def main():
         enc = model.encode(mel)
         prof = model.profile_decode(enc, L, stride=args.profile_stride)
         sa = prof["self_attn"]
-        sampled_t = list(range(0, L, args.profile_stride))
+        sampled_t = [t for t in range(L) if t % args.profile_stride == args.profile_stride // 2]
         rows = B * cfg.n_channels
         bytes_total = sum(self_attn_algorithmic_bytes(cfg, rows, t) for t in sampled_t) * cfg.n_dec_layers
         assert sa["launches"] == len(sampled_t) * cfg.n_dec_layers, (sa, len(sampled_t))
@@ -155,11 +165,12 @@ def main():
         result["roofline"] = {
             "kernel": "dec_attn_kernel<true> (decoder self-attention over the KV cache)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic(cfg, B, L),
             "avg_launch_us": 1e3 * avg_ms, "launches_timed": sa["launches"],
             "algorithmic_bytes_per_launch": bytes_total / sa["launches"],
-            "note": "bytes = rows*heads*(t+1)*64*2B*2 (K and V) averaged over sampled steps t = 0, stride, ...; "
-                    "duration = HIP events around each sampled launch on the launch stream",
+            "note": "bytes = rows*heads*(t+1)*64*2B*2 (K and V) averaged over sampled positions t = stride/2, 3*stride/2, ...; "
+                    "duration = HIP events around each sampled launch on the launch stream; traffic = FETCH_SIZE*2 + "
+                    "WRITE_SIZE per launch from profiles/r01_pmc_decode_attn.json (separate rocprofv3 --pmc passes)",
         }
         step_ms = {k: (v["ms_total"] / max(1, v["launches"])) * (cfg.n_dec_layers if k not in ("lm_head_gemm", "argmax_embed") else 1)
                    for k, v in prof.items()}

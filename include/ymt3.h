@@ -82,12 +82,18 @@ int ymt3_transcribe_segments(ymt3_handle h, const float* audio_dev, int B, int n
                              int32_t* tokens_dev, void* stream);
 
 /* Measurement hook (bench.py `roofline`): decode eagerly (no graph) and bracket every kernel launch of
- * every `stride`-th step with HIP events on `stream`; synchronises the stream before returning.
+ * every `stride`-th step (positions stride/2, 3*stride/2, ...) with HIP events on `stream`; synchronises the stream before returning.
  * Classes: 0 qkv+cache GEMM, 1 self-attention, 2 self O-proj, 3 cross Q GEMM, 4 cross-attention,
  * 5 cross O-proj, 6 FFN wi, 7 FFN wo, 8 lm_head, 9 argmax+embed.  Outputs are HOST arrays. */
 #define YMT3_PROFILE_CLASSES 16
 int ymt3_profile_decode(ymt3_handle h, const void* enc_dev, int B, int n_steps, int stride, int32_t* tokens_dev,
                         float* ms_by_class, int32_t* launches_by_class, void* stream);
+
+/* Measurement hook: later decode calls start at cache position `step0` instead of 0 (the cache below
+ * it holds whatever earlier calls left, so the TOKENS are meaningless; the memory traffic of positions
+ * step0.. is exactly that of a real decode).  Lets a profiler cover late positions in a short run:
+ * rocprofv3 7.2 --pmc segfaults beyond ~30k dispatches per process.  0 restores normal decoding. */
+int ymt3_set_profile_start(ymt3_handle h, int step0);
 
 /* Unit-test hooks: C = A(bf16 MxK) * W^T(bf16 NxK), f32 out; runs the encoder GEMM kernel. */
 int ymt3_test_gemm(ymt3_handle h, const void* a_dev, const void* w_dev, float* c_dev, int M, int N, int K, void* stream);

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = a.row0 + blockIdx.x;
     DecodeShared* sh = a.shared;
-    const int t = sh->step, n_steps = sh->n_steps;
+    const int t = sh->step, n_steps = sh->n_steps, col = t - sh->step0;   // col: index within this call
     const float* row = a.logits + (size_t)r * a.V;
 
     float bv = -3.4e38f;
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
             if (a.finished[r]) tok = a.pad_id;
             else if (tok == a.eos_id) a.finished[r] = 1;
         }
-        sh->tokens_out[(size_t)r * n_steps + t] = tok;
-        s_feed = sh->forced ? sh->forced[(size_t)r * n_steps + t] : tok;
+        sh->tokens_out[(size_t)r * n_steps + col] = tok;
+        s_feed = sh->forced ? sh->forced[(size_t)r * n_steps + col] : tok;
     }
     __syncthreads();
     const int feed = s_feed;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     const bf16_t* c = a.chan_embed ? a.chan_embed + (size_t)(r % a.n_channels) * a.d : nullptr;
     embed_row(a, r, e, c, sv);
     if (sh->logits_out) {
-        float* dst = sh->logits_out + ((size_t)r * n_steps + t) * a.V;
+        float* dst = sh->logits_out + ((size_t)r * n_steps + col) * a.V;
         for (int i = tid; i < a.V; i += 256) dst[i] = row[i];
     }
     // the last workgroup to finish advances the position; every workgroup has read `t` by then
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_chains, int n_steps, int32_t* tokens_out,
+__global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_chains, int n_steps, int step0, int32_t* tokens_out,
                                                           const int32_t* forced, float* logits_out) {
     const int r = blockIdx.x, tid = threadIdx.x;
     const bf16_t* e = a.embed + (size_t)a.pad_id * a.d;
@@ -396,7 +396,8 @@ __global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_ch
     if (tid == 0) a.finished[r] = 0;
     if (r == 0 && tid < n_chains) {          // a.shared is the array of per-chain loop states
         DecodeShared* sh = a.shared + tid;
-        sh->step = 0;
+        sh->step = step0;
+        sh->step0 = step0;
         sh->done_count = 0;
         sh->n_steps = n_steps;
         sh->tokens_out = tokens_out;
@@ -454,9 +455,9 @@ int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream) {
     return 0;
 }
 
-int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int32_t* tokens_out, const int32_t* forced,
+int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int step0, int32_t* tokens_out, const int32_t* forced,
                        float* logits_out, hipStream_t stream) {
     if (a.R <= 0) return 0;
-    decode_init_kernel<<<a.R, 256, 0, stream>>>(a, n_chains, n_steps, tokens_out, forced, logits_out);
+    decode_init_kernel<<<a.R, 256, 0, stream>>>(a, n_chains, n_steps, step0, tokens_out, forced, logits_out);
     return 0;
 }

@@ -49,7 +49,7 @@ struct DecodeShared {           // device-resident loop state, read by every dec
     int step;                   // position being decoded (tokens already in the cache)
     int done_count;             // ticket counter of the argmax kernel
     int n_steps;                // row stride of tokens_out / forced / logits_out
-    int pad0;
+    int step0;                  // first position of this call (0 except under ymt3_set_profile_start)
     int32_t* tokens_out;        // [R][n_steps]
     const int32_t* forced;      // [R][n_steps] or null
     float* logits_out;          // [R][n_steps][V] or null
@@ -105,5 +105,5 @@ struct ArgmaxArgs {
 };
 int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream);
 // all rows: h[r] = embed[pad] (+ chan_embed), finished = 0; a.shared[0..n_chains) reset
-int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int32_t* tokens_out, const int32_t* forced,
+int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int step0, int32_t* tokens_out, const int32_t* forced,
                        float* logits_out, hipStream_t stream);

@@ -84,6 +84,7 @@ struct ymt3_ctx {
     bool use_graph = true;
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
+    int prof_step0 = 0;                     // ymt3_set_profile_start: decode positions begin here (measurement only)
     std::vector<hipEvent_t> prof_ev;        // pairs
     std::vector<int> prof_cls;
 };
@@ -424,7 +425,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
 static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int32_t* tokens, const int32_t* forced,
                        float* logits_out, hipStream_t s, int prof_stride = 0) {
     const ymt3_config& k = h->cfg;
-    if (n_steps <= 0 || n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len);
+    if (n_steps <= 0 || h->prof_step0 + n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len - h->prof_step0);
     const int d = k.d_model, R = B * k.n_channels;
     // a6: cross-attention K/V of every decoder layer in one GEMM, stored as per-(segment, head) slabs
     GemmArgs g{enc, h->wkv_all, h->ckv, nullptr, B * h->T, k.n_dec_layers * 2 * h->inner, d, d, d, 0, h->T, k.n_heads, B};
@@ -438,14 +439,14 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
     // chains: contiguous, near-equal row ranges
     int n_chains = (!h->use_graph || prof_stride > 0) ? 1 : h->n_chains;
     if (n_chains > R) n_chains = R;
-    LAUNCH(launch_decode_init(a, n_chains, n_steps, tokens, forced, logits_out, s));
+    LAUNCH(launch_decode_init(a, n_chains, n_steps, h->prof_step0, tokens, forced, logits_out, s));
     int row0[9];
     row0[0] = 0;
     for (int c = 0; c < n_chains; ++c) row0[c + 1] = row0[c] + R / n_chains + (c < R % n_chains ? 1 : 0);
 
     if (!h->use_graph || prof_stride > 0) {
         for (int t = 0; t < n_steps; ++t) {
-            h->prof_on = prof_stride > 0 && (t % prof_stride) == 0;
+            h->prof_on = prof_stride > 0 && (t % prof_stride) == prof_stride / 2;   // mid-stride: unbiased mean position
             int rc = launch_step(h, B, 0, R, h->shared, s);
             h->prof_on = false;
             if (rc) return rc;
@@ -541,3 +542,10 @@ extern "C" int ymt3_profile_decode(ymt3_handle h, const void* enc_dev, int B, in
     return YMT3_OK;
 }
 static_assert(PC_COUNT <= YMT3_PROFILE_CLASSES, "profile class table");
+
+extern "C" int ymt3_set_profile_start(ymt3_handle h, int step0) {
+    if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (step0 < 0 || step0 >= h->cfg.max_decode_len) FAIL(YMT3_ERR_ARG, "step0=%d outside [0, %d)", step0, h->cfg.max_decode_len);
+    h->prof_step0 = step0;
+    return YMT3_OK;
+}
