@@ -21,32 +21,45 @@
 //                       stream, and the step counter advance by the last workgroup to finish.
 //
 // Oracle: oracle/ymt3_oracle.py::decoder_step / greedy_decode.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int DKV = 64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // 512 threads = 8 waves; one workgroup = a (16*MT rows) x 16 columns output tile over the full K, each
 // wave owning K/8 of the reduction.  MT = 1 (16 rows) for R <= 128 keeps every workgroup's operand
-// traffic small (the per-CU load path, ~64 B/clk, is what bounds these kernels, not HBM): 16 rows of A
-// plus a 16 x K weight tile; workgroups that share a weight tile are placed on one XCD (same
-// blockIdx % 8) so its re-reads hit that XCD's L2.  MT = 4 (64 rows) for the multi-channel row counts.
-// Every operand fragment goes global -> VGPR with all loads issued before the first use (one memory
-// round trip per kernel); LDS carries only the fixed-order 8-way partial-sum reduction.  The RMS
-// norm needs sum(x^2) over the FULL row, which no single wave sees: it is carried between kernels as
-// per-row partial sums `ssq[tile][row]` written by whoever last wrote the residual stream (the 32
-// column tiles of the RESID epilogue, or the embedding gather) and summed here in a fixed order.
+// traffic small (the per-CU load path is what bounds these kernels, not HBM); workgroups that share a
+// weight tile are placed on one XCD (same blockIdx % 8) so its re-reads hit that XCD's L2.
+//
+// Operand path (MT = 1): every wave pulls ITS K-slice of the 16 activation rows and 16 weight rows
+// with fully coalesced 16-byte loads (8..32 consecutive lanes per row = whole 128-byte lines), all
+// issued up front (one memory round trip), parks them in a wave-private LDS strip, and reads them
+// back in MFMA fragment order with ds_read_b128.  Fragment-shaped global loads (16 rows x 64 B per
+// instruction) measured 3-4x slower for the same bytes (profiles/r01_notes.md).  No workgroup barrier
+// is needed for the strip: only the owning wave touches it and LDS executes a wave's ops in order.
+// MT = 4 (multi-channel row counts) keeps direct fragment loads: its 64-row strips would not fit LDS.
+//
+// The RMS norm needs sum(x^2) over the FULL row, which no single wave sees: it is carried between
+// kernels as per-row partial sums `ssq[tile][row]` written by whoever last wrote the residual stream
+// (the 32 column tiles of the RESID epilogue, or the embedding gather) and summed in a fixed order.
 template <int MODE, int K, int MT>
 __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     constexpr bool NORM = (MODE != DG_RESID);
     constexpr int KW = K / 8;            // K slice per wave
     constexpr int KS = KW / 32;          // MFMA k-steps per wave
     constexpr int ROWS = 16 * MT;
-    __shared__ __attribute__((aligned(16))) float red[8 * ROWS * 16];
-    __shared__ float sscale[ROWS];
+    constexpr int PITCH = KW * 2 + 16;   // bytes per strip row (bf16 slice + 16 B pad against bank conflicts)
+    constexpr int STRIP = 16 * PITCH;    // one operand strip (16 rows) of one wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);                    // [8][ROWS][16]
+    float* sscale = red + 8 * ROWS * 16;                            // [ROWS]
+    char* strips = smem + (8 * ROWS * 16 + ROWS) * 4;               // MT == 1: [8 waves][A strip | W strip]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -63,7 +76,6 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
         nt_idx = blockIdx.x / n_mt;
     }
     const int n0 = nt_idx * 16, m0 = a.row0 + mt_idx * ROWS, m_end = a.row0 + a.R;
-    const int kb = wave * KW + g * 8;
 
     // epilogue ownership: thread -> (row mr, 2 columns nq)
     const bool epi = tid < ROWS * 8;
@@ -79,76 +91,145 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const bf16_t* wrow = a.W + (size_t)(n0 + li) * K + kb;
-    bf16x8 wf[KS];
+    if constexpr (MT == 1) {
+        char* sA = strips + wave * 2 * STRIP;
+        char* sW = sA + STRIP;
+        // weight slice: LPRW lanes cover one row's KW bf16
+        constexpr int LPRW = KW * 2 / 16, RPIW = 64 / LPRW, NIW = 16 / RPIW;
+        u32x4 wv[NIW];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + ks * 32));
-
-    int mrow[MT];
+        for (int i = 0; i < NIW; ++i) {
+            const int row = i * RPIW + lane / LPRW, ch = lane % LPRW;
+            wv[i] = *reinterpret_cast<const u32x4*>(a.W + (size_t)(n0 + row) * K + wave * KW + ch * 8);
+        }
+        if constexpr (NORM) {
+            constexpr int LPRX = KW * 4 / 16, RPIX = 64 / LPRX, NIX = 16 / RPIX;   // fp32 rows
+            f32x4 xv[NIX];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int mm = m0 + mt * 16 + li;
-        mrow[mt] = mm < m_end ? mm : m_end - 1;
-    }
-
-    if constexpr (NORM) {
-        float4 xv[MT][KS][2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float4* px = reinterpret_cast<const float4*>(a.x_f32 + (size_t)mrow[mt] * K + kb + ks * 32);
-                xv[mt][ks][0] = px[0];
-                xv[mt][ks][1] = px[1];
+            for (int i = 0; i < NIX; ++i) {
+                int mm = m0 + i * RPIX + lane / LPRX;
+                mm = mm < m_end ? mm : m_end - 1;
+                xv[i] = *reinterpret_cast<const f32x4*>(a.x_f32 + (size_t)mm * K + wave * KW + (lane % LPRX) * 4);
             }
-        float4 gv[KS][2];
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gain + wave * KW + (lane % LPRX) * 4);
+            float ss = 0.f;
+            if (epi) {
+                const int mm = m < m_end ? m : m_end - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ss += a.ssq[(size_t)((tid & 7) * 4 + j) * a.ssq_stride + mm];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // every operand load is in flight before anything waits
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            ss += __shfl_xor(ss, 4, 64);
+            if (epi && (tid & 7) == 0) sscale[mr] = rsqrtf(ss / (float)K + a.eps);
+#pragma unroll
+            for (int i = 0; i < NIW; ++i)
+                *reinterpret_cast<u32x4*>(sW + (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16) = wv[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NIX; ++i) {
+                const int row = i * RPIX + lane / LPRX;
+                const float sc = sscale[row];
+                *reinterpret_cast<uint2*>(sA + row * PITCH + (lane % LPRX) * 8) =
+                    make_uint2(pack_bf16x2(xv[i][0] * sc * gv[0], xv[i][1] * sc * gv[1]),
+                               pack_bf16x2(xv[i][2] * sc * gv[2], xv[i][3] * sc * gv[3]));
+            }
+        } else {
+            constexpr int NIA = NIW;
+            u32x4 av[NIA];
+#pragma unroll
+            for (int i = 0; i < NIA; ++i) {
+                int mm = m0 + i * RPIW + lane / LPRW;
+                mm = mm < m_end ? mm : m_end - 1;
+                av[i] = *reinterpret_cast<const u32x4*>(a.a_bf16 + (size_t)mm * K + wave * KW + (lane % LPRW) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // every operand load is in flight before anything waits
+#pragma unroll
+            for (int i = 0; i < NIW; ++i) {
+                const int off = (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16;
+                *reinterpret_cast<u32x4*>(sW + off) = wv[i];
+                *reinterpret_cast<u32x4*>(sA + off) = av[i];
+            }
+        }
+        // fragment order read-back (wave-private strips: in-order LDS, no barrier)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const float4* pg = reinterpret_cast<const float4*>(a.gain + kb + ks * 32);
-            gv[ks][0] = pg[0];
-            gv[ks][1] = pg[1];
-        }
-        // row scales from the partial sums: thread (row, part) adds 4 tiles, 8 parts combine by shuffle
-        float ss = 0.f;
-        if (epi) {
-            const int mm = m < m_end ? m : m_end - 1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ss += a.ssq[(size_t)((tid & 7) * 4 + j) * a.ssq_stride + mm];
-        }
-        __builtin_amdgcn_sched_barrier(0);   // all operand loads are in flight before anything waits
-        ss += __shfl_xor(ss, 1, 64);
-        ss += __shfl_xor(ss, 2, 64);
-        ss += __shfl_xor(ss, 4, 64);
-        if (epi && (tid & 7) == 0) sscale[mr] = rsqrtf(ss / (float)K + a.eps);
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float sc = sscale[mt * 16 + li];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float4 x0 = xv[mt][ks][0], x1 = xv[mt][ks][1], g0 = gv[ks][0], g1 = gv[ks][1];
-                bf16x8 af;
-                af[0] = (__bf16)(x0.x * sc * g0.x); af[1] = (__bf16)(x0.y * sc * g0.y);
-                af[2] = (__bf16)(x0.z * sc * g0.z); af[3] = (__bf16)(x0.w * sc * g0.w);
-                af[4] = (__bf16)(x1.x * sc * g1.x); af[5] = (__bf16)(x1.y * sc * g1.y);
-                af[6] = (__bf16)(x1.z * sc * g1.z); af[7] = (__bf16)(x1.w * sc * g1.w);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af, acc[mt], 0, 0, 0);
-            }
+            const int off = li * PITCH + (ks * 32 + g * 8) * 2;
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + off);
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + off);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[0], 0, 0, 0);
         }
     } else {
-        bf16x8 af[MT][KS];
+        const int kb = wave * KW + g * 8;
+        const bf16_t* wrow = a.W + (size_t)(n0 + li) * K + kb;
+        bf16x8 wf[KS];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + ks * 32));
+        int mrow[MT];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                af[mt][ks] = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const uint4*>(a.a_bf16 + (size_t)mrow[mt] * K + kb + ks * 32));
-        __builtin_amdgcn_sched_barrier(0);   // keep every load above the first MFMA: one round trip, not KS of them
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int mt = 0; mt < MT; ++mt) {
+            const int mm = m0 + mt * 16 + li;
+            mrow[mt] = mm < m_end ? mm : m_end - 1;
+        }
+        if constexpr (NORM) {
+            float4 xv[MT][KS][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[mt][ks], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const float4* px = reinterpret_cast<const float4*>(a.x_f32 + (size_t)mrow[mt] * K + kb + ks * 32);
+                    xv[mt][ks][0] = px[0];
+                    xv[mt][ks][1] = px[1];
+                }
+            float4 gv[KS][2];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4* pg = reinterpret_cast<const float4*>(a.gain + kb + ks * 32);
+                gv[ks][0] = pg[0];
+                gv[ks][1] = pg[1];
+            }
+            float ss = 0.f;
+            if (epi) {
+                const int mm = m < m_end ? m : m_end - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ss += a.ssq[(size_t)((tid & 7) * 4 + j) * a.ssq_stride + mm];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            ss += __shfl_xor(ss, 4, 64);
+            if (epi && (tid & 7) == 0) sscale[mr] = rsqrtf(ss / (float)K + a.eps);
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float sc = sscale[mt * 16 + li];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const float4 x0 = xv[mt][ks][0], x1 = xv[mt][ks][1], g0 = gv[ks][0], g1 = gv[ks][1];
+                    bf16x8 af;
+                    af[0] = (__bf16)(x0.x * sc * g0.x); af[1] = (__bf16)(x0.y * sc * g0.y);
+                    af[2] = (__bf16)(x0.z * sc * g0.z); af[3] = (__bf16)(x0.w * sc * g0.w);
+                    af[4] = (__bf16)(x1.x * sc * g1.x); af[5] = (__bf16)(x1.y * sc * g1.y);
+                    af[6] = (__bf16)(x1.z * sc * g1.z); af[7] = (__bf16)(x1.w * sc * g1.w);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af, acc[mt], 0, 0, 0);
+                }
+            }
+        } else {
+            bf16x8 af[MT][KS];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    af[mt][ks] = __builtin_bit_cast(
+                        bf16x8, *reinterpret_cast<const uint4*>(a.a_bf16 + (size_t)mrow[mt] * K + kb + ks * 32));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[mt][ks], acc[mt], 0, 0, 0);
+        }
     }
 
     // fixed-order cross-wave reduction: red[wave][row][n (16)]
@@ -181,8 +262,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
         if (live && (tid & 7) == 0) a.ssq[(size_t)nt_idx * a.ssq_stride + m] = q;
     } else if constexpr (MODE == DG_NORM_LOGITS) {
         if (live) *reinterpret_cast<float2*>(a.out_f32 + (size_t)m * a.N + n) = s;
-    } else {
-        if (!live) return;
+    } else if (live) {
         if constexpr (MODE == DG_NORM_BF16_RELU) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); }
         const uint32_t pk = pack_bf16x2(s.x, s.y);
         if constexpr (MODE == DG_NORM_QKV_CACHE) {
@@ -202,11 +282,22 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// sum over the 8 lanes that share one key (lane & 7 = 16-byte chunk of the 128-byte row): DPP moves,
+// no LDS crossbar (ds_bpermute) in the inner loop
+#define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float sum8(float v) {
+    v += DPP_F(v, 0xB1);     // quad_perm [1,0,3,2]  : lane ^ 1
+    v += DPP_F(v, 0x4E);     // quad_perm [2,3,0,1]  : lane ^ 2
+    v += DPP_F(v, 0x141);    // row_half_mirror      : lane -> 7 - lane within its 8 (other quad, already summed)
+    return v;
+}
+
 template <bool SELF>
 __global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
     constexpr int NW = 8;                       // waves per (row, head): 16 waves / CU keep > 12 MB in flight chip-wide
     __shared__ float sm[NW], sl[NW], sacc[NW][DKV];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane & 7, kg = lane >> 3;
     const int r = a.row0 + blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int n_keys = SELF ? a.shared->step + 1 : a.n_keys_const;
@@ -217,7 +308,6 @@ __global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
     const float* bias = SELF ? a.bias + (size_t)h * a.bias_stride : nullptr;
 
     // q stays packed (4 x bf16x2); halves are widened to fp32 at use
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 qp = *reinterpret_cast<const u32x4*>(a.q + ((size_t)r * a.H + h) * DKV + sub * 8);
 
     float m = -1.0e30f, l = 0.f, acc[8];
@@ -226,43 +316,48 @@ __global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
 
     // The self-attention cache (up to 805 MB) is read exactly once per step: non-temporal loads keep it
     // from evicting the weights (42 MB) and the cross-attention K/V (201 MB at 64 segments), both
-    // re-read every step, out of the 256 MB Infinity Cache.  16 x 16-byte loads in flight per lane.
+    // re-read every step, out of the 256 MB Infinity Cache.  Up to 16 x 16-byte loads in flight per lane;
+    // blocks of 64 keys that lie wholly beyond n_keys are skipped wave-uniformly (loads AND math), so
+    // early positions do not pay for the unrolled tail.
     constexpr int U = SELF ? 8 : 4;            // cross: 8 waves x 8 keys x 4 = 256 frames in one shot
-    for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {     // wave-uniform trip count
+    auto block = [&](int kw, int nblk, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;         // FULL: all U blocks valid, branch-free
         const int k0 = kw + kg;
         u32x4 ku[U], vu[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int key = k0 + 8 * NW * u;
-            ok[u] = key < n_keys;
-            const int kc = ok[u] ? key : 0;
-            if constexpr (SELF) {
-                ku[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV));
-                vu[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV));
-            } else {
-                ku[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV);
-                vu[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV);
+            ok[u] = FULL || key < n_keys;
+            if (FULL || u < nblk) {
+                const int kc = ok[u] ? key : kw;
+                if constexpr (SELF) {
+                    ku[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV));
+                    vu[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV));
+                } else {
+                    ku[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV);
+                    vu[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV);
+                }
             }
         }
         float sc[U];
         float mn = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float s = 0.f;
+            if (FULL || u < nblk) {
+                float s = 0.f;
+                // plain fp32 FMAs on the unpacked halves: v_dot2c_f32_bf16 chains gave O(1) wrong scores on
+                // gfx950 / ROCm 7.2 in this kernel (bisected on hardware), so the packed dot is not used
 #pragma unroll
-            // plain fp32 FMAs on the unpacked halves: v_dot2c_f32_bf16 chains gave O(1) wrong scores on
-            // gfx950 / ROCm 7.2 in this kernel (bisected on hardware), so the packed dot is not used
-            for (int j = 0; j < 4; ++j) {
-                s = fmaf(__uint_as_float(qp[j] << 16), __uint_as_float(ku[u][j] << 16), s);
-                s = fmaf(__uint_as_float(qp[j] & 0xffff0000u), __uint_as_float(ku[u][j] & 0xffff0000u), s);
+                for (int j = 0; j < 4; ++j) {
+                    s = fmaf(__uint_as_float(qp[j] << 16), __uint_as_float(ku[u][j] << 16), s);
+                    s = fmaf(__uint_as_float(qp[j] & 0xffff0000u), __uint_as_float(ku[u][j] & 0xffff0000u), s);
+                }
+                s = sum8(s);
+                if (SELF && ok[u]) s += bias[n_keys - 1 - (k0 + 8 * NW * u)];
+                sc[u] = s;
+                if (ok[u]) mn = fmaxf(mn, s);
             }
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            if (SELF && ok[u]) s += bias[n_keys - 1 - (k0 + 8 * NW * u)];
-            sc[u] = s;
-            if (ok[u]) mn = fmaxf(mn, s);
         }
         const float rescale = __expf(m - mn);
         l *= rescale;
@@ -270,15 +365,23 @@ __global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
         for (int d = 0; d < 8; ++d) acc[d] *= rescale;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float p = ok[u] ? __expf(sc[u] - mn) : 0.f;
-            l += p;
+            if (FULL || u < nblk) {
+                const float p = ok[u] ? __expf(sc[u] - mn) : 0.f;
+                l += p;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[2 * j] = fmaf(p, __uint_as_float(vu[u][j] << 16), acc[2 * j]);
-                acc[2 * j + 1] = fmaf(p, __uint_as_float(vu[u][j] & 0xffff0000u), acc[2 * j + 1]);
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * j] = fmaf(p, __uint_as_float(vu[u][j] << 16), acc[2 * j]);
+                    acc[2 * j + 1] = fmaf(p, __uint_as_float(vu[u][j] & 0xffff0000u), acc[2 * j + 1]);
+                }
             }
         }
         m = mn;
+    };
+    for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {     // wave-uniform trip count
+        // wave-uniform: blocks of 64 keys holding at least one valid key for this wave
+        const int nblk = (n_keys - kw + 8 * NW - 1) / (8 * NW);
+        if (n_keys - kw >= 8 * NW * U) block(kw, U, std::true_type{});
+        else block(kw, nblk, std::false_type{});
     }
     // merge the 8 key groups of the wave (lanes with equal `sub`)
 #pragma unroll
@@ -406,22 +509,45 @@ __global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_ch
     }
 }
 
+template <int MODE, int K, int MT>
+constexpr size_t dg_lds_bytes() {
+    return (size_t)(8 * 16 * MT * 16 + 16 * MT) * 4 + (MT == 1 ? (size_t)8 * 2 * 16 * (K / 8 * 2 + 16) : 0);
+}
+
 template <int MODE, int K>
 int launch_dg(const DecGemmArgs& a, hipStream_t stream) {
+    if (a.W == nullptr) {   // attribute-only call from init_decode_kernels(): > 64 KB of dynamic LDS needs opting in
+        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, 1>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K, 1>());
+        const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, 4>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K, 4>());
+        return (e1 == hipSuccess && e4 == hipSuccess) ? 0 : -2;
+    }
     if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;   // the norm consumers sum exactly SSQ_TILES partials
     if (a.R <= 128) {
         const int n_mt = (a.R + 15) / 16;
-        dec_gemm_kernel<MODE, K, 1><<<(a.N / 16) * n_mt, 512, 0, stream>>>(a);
+        dec_gemm_kernel<MODE, K, 1><<<(a.N / 16) * n_mt, 512, dg_lds_bytes<MODE, K, 1>(), stream>>>(a);
     } else {
         const int n_mt = (a.R + 63) / 64;
-        dec_gemm_kernel<MODE, K, 4><<<(a.N / 16) * n_mt, 512, 0, stream>>>(a);
+        dec_gemm_kernel<MODE, K, 4><<<(a.N / 16) * n_mt, 512, dg_lds_bytes<MODE, K, 4>(), stream>>>(a);
     }
     return 0;
 }
 
 }  // namespace
 
-int init_decode_kernels() { return 0; }
+int init_decode_kernels() {
+    DecGemmArgs z{};
+    int rc = 0;
+    rc |= launch_dg<DG_RESID, 512>(z, nullptr);
+    rc |= launch_dg<DG_RESID, 1024>(z, nullptr);
+    rc |= launch_dg<DG_RESID, 2048>(z, nullptr);
+    rc |= launch_dg<DG_NORM_QKV_CACHE, 512>(z, nullptr);
+    rc |= launch_dg<DG_NORM_BF16, 512>(z, nullptr);
+    rc |= launch_dg<DG_NORM_BF16_RELU, 512>(z, nullptr);
+    rc |= launch_dg<DG_NORM_LOGITS, 512>(z, nullptr);
+    return rc;
+}
 
 int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;

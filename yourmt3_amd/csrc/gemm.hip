@@ -22,8 +22,9 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 8 + (chunk
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ uint4 sA[2][BM * 8];
-    __shared__ uint4 sW[2][BN * 8];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // first-class vectors: HIP's uint4 struct arrays went to scratch
+    __shared__ u32x4 sA[2][BM * 8];
+    __shared__ u32x4 sW[2][BN * 8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -43,15 +44,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rw[4];
+    u32x4 ra[4], rw[4];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7;
             int am = m0 + row;
             am = am < g.M ? am : g.M - 1;
-            ra[i] = *reinterpret_cast<const uint4*>(g.A + (size_t)am * g.lda + kt * BK + ch * 8);
-            rw[i] = *reinterpret_cast<const uint4*>(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + ch * 8);
+            ra[i] = *reinterpret_cast<const u32x4*>(g.A + (size_t)am * g.lda + kt * BK + ch * 8);
+            rw[i] = *reinterpret_cast<const u32x4*>(g.W + (size_t)(n0 + row) * g.ldw + kt * BK + ch * 8);
         }
     };
     auto lstore = [&](int buf) {

@@ -370,48 +370,56 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     GET(h, "dec.bias_dist", 0u, const_cast<float**>(&bias_dist), (size_t)H * L);
     bf16_t* w;
     float* f;
+    // every weight of the step up front
+    struct LayerW { float *ln1, *ln2, *ln3; bf16_t *wqkv, *wo, *wq_c, *wo_c, *wi, *wo2; };
+    std::vector<LayerW> LW(k.n_dec_layers);
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const std::string p = "dec." + std::to_string(l) + ".";
+        GET(h, p + "ln1", 0u, &LW[l].ln1, (size_t)d);
+        GET(h, p + "ln2", 0u, &LW[l].ln2, (size_t)d);
+        GET(h, p + "ln3", 0u, &LW[l].ln3, (size_t)d);
+        GET(h, p + "wqkv", 1u, &LW[l].wqkv, (size_t)3 * inner * d);
+        GET(h, p + "wo", 1u, &LW[l].wo, (size_t)d * inner);
+        GET(h, p + "wq_c", 1u, &LW[l].wq_c, (size_t)inner * d);
+        GET(h, p + "wo_c", 1u, &LW[l].wo_c, (size_t)d * inner);
+        GET(h, p + "wi", 1u, &LW[l].wi, (size_t)k.d_ff * d);
+        GET(h, p + "wo2", 1u, &LW[l].wo2, (size_t)d * k.d_ff);
+    }
+    bf16_t* lm_head;
+    GET(h, "dec.lm_head", 1u, &lm_head, (size_t)k.vocab * d);
+    (void)w;
+    for (int l = 0; l < k.n_dec_layers; ++l) {
+        const LayerW& W = LW[l];
         DecGemmArgs a{};
         a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
         // self-attention block
-        GET(h, p + "ln1", 0u, &f, (size_t)d);
-        GET(h, p + "wqkv", 1u, &w, (size_t)3 * inner * d);
-        a.x_f32 = h->h_dec; a.gain = f; a.W = w; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
+        a.x_f32 = h->h_dec; a.gain = W.ln1; a.W = W.wqkv; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
         a.kcache = h->kcache + l * layer_cache; a.vcache = h->vcache + l * layer_cache;
         PLAUNCH(PC_QKV, launch_dec_gemm(DG_NORM_QKV_CACHE, a, s));
         DecAttnArgs t{};
         t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
         t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
         PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
-        GET(h, p + "wo", 1u, &w, (size_t)d * inner);
-        a.a_bf16 = h->dattn; a.W = w; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
+        a.a_bf16 = h->dattn; a.W = W.wo; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
         PLAUNCH(PC_SELF_O, launch_dec_gemm(DG_RESID, a, s));
         // cross-attention block
-        GET(h, p + "ln2", 0u, &f, (size_t)d);
-        GET(h, p + "wq_c", 1u, &w, (size_t)inner * d);
-        a.gain = f; a.W = w; a.N = inner; a.K = d; a.out_bf16 = h->dq;
+        a.gain = W.ln2; a.W = W.wq_c; a.N = inner; a.K = d; a.out_bf16 = h->dq;
         PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
         t.k = h->ckv + (size_t)(2 * l) * slab; t.v = h->ckv + (size_t)(2 * l + 1) * slab; t.bias = nullptr;
         t.n_keys_const = h->T; t.slab_keys = h->T; t.rows_per_kv = k.n_channels;
         PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
-        GET(h, p + "wo_c", 1u, &w, (size_t)d * inner);
-        a.a_bf16 = h->dattn; a.W = w; a.N = d; a.K = inner;
+        a.a_bf16 = h->dattn; a.W = W.wo_c; a.N = d; a.K = inner;
         PLAUNCH(PC_CROSS_O, launch_dec_gemm(DG_RESID, a, s));
         // feed-forward block
-        GET(h, p + "ln3", 0u, &f, (size_t)d);
-        GET(h, p + "wi", 1u, &w, (size_t)k.d_ff * d);
-        a.gain = f; a.W = w; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
+        a.gain = W.ln3; a.W = W.wi; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
         PLAUNCH(PC_FFN_WI, launch_dec_gemm(DG_NORM_BF16_RELU, a, s));
-        GET(h, p + "wo2", 1u, &w, (size_t)d * k.d_ff);
-        a.a_bf16 = h->dff; a.W = w; a.N = d; a.K = k.d_ff;
+        a.a_bf16 = h->dff; a.W = W.wo2; a.N = d; a.K = k.d_ff;
         PLAUNCH(PC_FFN_WO, launch_dec_gemm(DG_RESID, a, s));
     }
     DecGemmArgs a{};
     a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
     GET(h, "dec.ln_f", 0u, &f, (size_t)d);
-    GET(h, "dec.lm_head", 1u, &w, (size_t)k.vocab * d);
-    a.x_f32 = h->h_dec; a.gain = f; a.W = w; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
+    a.x_f32 = h->h_dec; a.gain = f; a.W = lm_head; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
     PLAUNCH(PC_LM_HEAD, launch_dec_gemm(DG_NORM_LOGITS, a, s));
     ArgmaxArgs g{};
     g.logits = h->logits; g.h = h->h_dec; g.shared = shared; g.finished = h->finished; g.ssq = h->ssq; g.ssq_stride = h->maxR; g.row0 = row0;
