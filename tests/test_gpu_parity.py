@@ -217,6 +217,40 @@ def test_multichannel_rows_share_the_segment_encoder():
     assert not torch.equal(ref_t[:, 0], ref_t[:, 1])             # channels really differ
 
 
+def test_multichannel_beyond_128_rows_uses_the_64_row_tiles():
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=16, n_channels=13)
+    m = _model(cfg, max_batch=12)                      # 156 rows -> dec_gemm MT = 4 path
+    a = O.synthetic_audio(12, cfg)
+    _, enc = O.encode(a, m.weights, cfg, True)
+    ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, 6, True, return_logits=True)
+    got_t, got_l = m.decode(enc.bfloat16().cuda(), 6, forced=ref_t.cuda(), return_logits=True)
+    m.close()
+    assert (got_l.cpu() - ref_l).abs().max().item() < 0.06
+    safe = _margin(ref_l) >= TAU
+    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+
+
+def test_512_frame_segments():
+    cfg = YMT3Config(segment_samples=65535, max_decode_len=16)
+    m = _model(cfg, max_batch=2)
+    a = O.synthetic_audio(2, cfg)
+    mel_ref, enc_ref = O.encode(a, m.weights, cfg, True)
+    mel = m.logmel(a.cuda())
+    assert mel.shape == (2, 512, 128) and (mel.cpu() - mel_ref).abs().max().item() < 1e-3
+    assert (m.encode(mel).float().cpu() - enc_ref).abs().max().item() <= 0.0625
+    m.close()
+
+
+def test_transcribe_writes_a_midi_file(small, tmp_path):
+    from yourmt3_amd.midi import read_midi_notes
+    from yourmt3_amd.transcribe import transcribe
+    audio = O.synthetic_audio(1, YMT3Config(segment_samples=3 * 8191))[0].numpy()      # 3 segments of the small config
+    path, notes = transcribe(small, audio, bsz=2, output_dir=str(tmp_path), max_token_length=32, return_notes=True)
+    data = open(path, "rb").read()
+    assert data[:4] == b"MThd"
+    assert len(read_midi_notes(data)) == len(notes)       # random weights: any notes, but a well-formed file
+
+
 def test_bad_arguments_raise(small):
     from yourmt3_amd._lib import YMT3Error
     e = torch.zeros(1, SMALL.n_frames, SMALL.d_model, dtype=torch.bfloat16).cuda()

@@ -1,0 +1,198 @@
+"""Host-side (CPU) tests of the token vocabulary, TaskManager state machines, MIDI writer, audio slicing and the
+`transcribe()` flow.  The reference has no tests for these; these are this build's known-answer
+and round-trip tests ("pure integer, exact-parity testable; needs its own KATs")."""
+import os
+import random
+import wave
+
+import numpy as np
+import pytest
+
+from yourmt3_amd.audio import load_wav, resample, slice_padded_array
+from yourmt3_amd.config import YMT3Config
+from yourmt3_amd.midi import notes_to_midi_bytes, read_midi_notes, write_midi
+from yourmt3_amd.task_manager import (MC13_GROUPS, Note, NoteEvent, TaskManager, note_events_to_notes, DRUM_PROGRAM)
+from yourmt3_amd.transcribe import transcribe
+from yourmt3_amd.vocab import Codec, Event, EOS, PAD, UNK
+
+SEG = 32767 / 16000.0
+
+
+def test_codec_is_a_bijection_and_fits_the_head():
+    c = Codec()
+    assert c.size == 598 <= YMT3Config().vocab
+    seen = set()
+    for t in range(3, c.size):
+        ev = c.decode(t)
+        assert c.encode(ev) == t and ev not in seen
+        seen.add(ev)
+    assert c.decode(PAD).type == c.decode(EOS).type == c.decode(UNK).type == c.decode(c.size).type == "special"
+    assert c.decode(c.encode(Event("shift", 206))) == Event("shift", 206)
+    with pytest.raises(ValueError):
+        c.encode(Event("shift", 207))
+    with pytest.raises(ValueError):
+        c.encode(Event("pitch", 128))
+
+
+def _events(notes):
+    ev = []
+    for n in notes:
+        if n.is_drum:
+            ev.append(NoteEvent(n.onset, True, DRUM_PROGRAM, 1, n.pitch))
+        else:
+            ev += [NoteEvent(n.onset, False, n.program, 1, n.pitch), NoteEvent(n.offset, False, n.program, 0, n.pitch)]
+    return sorted(ev)
+
+
+def _tokenize(tm, notes, n_seg, max_len):
+    ev = _events(notes)
+    rows = []
+    for i in range(n_seg):
+        s, e = i * SEG, (i + 1) * SEG
+        ties = [(n.program, n.pitch) for n in notes if not n.is_drum and n.onset < s < n.offset]
+        rows.append(tm.tokenizer.encode_segment([x for x in ev if s <= x.time < e], ties, s, max_len=max_len))
+    return np.array(rows, dtype=np.int32)
+
+
+def _grid(t, seg_start):            # what 10 ms quantisation relative to the segment start does to a time
+    return seg_start + round((t - seg_start) * 100) / 100
+
+
+def test_known_answer_token_stream():
+    tm = TaskManager()
+    c = tm.codec
+    toks = tm.tokenizer.encode_segment(_events([Note(0.10, 0.50, False, 0, 60)]), [(40, 64)], 0.0, max_len=16)
+    expect = [c.encode(Event("program", 40)), c.encode(Event("pitch", 64)), c.encode(Event("tie", 0)),
+              c.encode(Event("shift", 10)), c.encode(Event("velocity", 1)), c.encode(Event("program", 0)), c.encode(Event("pitch", 60)),
+              c.encode(Event("shift", 40)), c.encode(Event("velocity", 0)), c.encode(Event("pitch", 60)), EOS]
+    assert toks == expect + [PAD] * 5
+    ev, ties, bad = tm.tokenizer.decode_segment(toks, 0.0)
+    assert ties == [(40, 64)] and bad == 0
+    assert ev == [NoteEvent(0.1, False, 0, 1, 60), NoteEvent(0.5, False, 0, 0, 60)]
+
+
+def test_notes_roundtrip_across_segments_with_ties_and_drums():
+    rng = random.Random(7)
+    tm = TaskManager()
+    notes = []
+    for _ in range(60):
+        on = round(rng.uniform(0, 7.5), 2)
+        if rng.random() < 0.2:
+            notes.append(Note(on, on + 0.01, True, DRUM_PROGRAM, rng.choice([36, 38, 42])))
+        else:
+            notes.append(Note(on, round(on + rng.uniform(0.05, 3.0), 2), False, rng.choice([0, 24, 40, 129]), rng.randrange(30, 90)))
+    # no two melodic notes of the same (program, pitch) may overlap for an exact round trip
+    uniq, keep = {}, []
+    for n in sorted(notes):
+        k = (n.program, n.pitch)
+        if n.is_drum or k not in uniq or uniq[k] < n.onset - 0.02:
+            keep.append(n)
+            if not n.is_drum:
+                uniq[k] = n.offset
+    n_seg = 5
+    toks = _tokenize(tm, keep, n_seg, 512)
+    got = tm.tokens_to_notes([toks[:2, None, :], toks[2:, None, :]], [i * SEG for i in range(n_seg)], end_sec=n_seg * SEG)
+    assert len(got) == len(keep)
+    for g, n in zip(sorted(got, key=lambda x: (x.program, x.pitch, x.onset)), sorted(keep, key=lambda x: (x.program, x.pitch, x.onset))):
+        assert (g.is_drum, g.program, g.pitch) == (n.is_drum, n.program, n.pitch)
+        assert abs(g.onset - n.onset) <= 0.0051 and (n.is_drum or abs(g.offset - n.offset) <= 0.0051)
+
+
+def test_untied_note_is_closed_at_the_next_segment_start_and_dangling_offsets_are_dropped():
+    tm = TaskManager()
+    c = tm.codec
+    seg0 = [c.encode(Event("tie", 0)), c.encode(Event("shift", 50)), c.encode(Event("velocity", 1)), c.encode(Event("program", 0)),
+            c.encode(Event("pitch", 60)), EOS]
+    seg1 = [c.encode(Event("tie", 0)), c.encode(Event("shift", 10)), c.encode(Event("velocity", 0)), c.encode(Event("pitch", 72)), EOS]
+    segs = tm.detokenize_list_batches([np.array([seg0 + [PAD] * 4]), np.array([seg1 + [PAD] * 5])], [0.0, SEG])
+    notes = note_events_to_notes(segs, end_sec=2 * SEG)
+    assert notes == [Note(0.5, SEG, False, 0, 60)]
+
+
+def test_malformed_tokens_are_counted_not_fatal():
+    tm = TaskManager()
+    c = tm.codec
+    row = np.array([c.encode(Event("drum", 36)), UNK, 1500, c.encode(Event("tie", 0)), c.encode(Event("shift", 3)),
+                    c.encode(Event("drum", 38)), EOS, c.encode(Event("pitch", 1))])
+    segs, bad = tm.detokenize_list_batches([row[None]], [0.0], return_events=True)
+    assert bad == 3                                          # drum inside the tie section, UNK, id beyond the codec
+    assert segs[0][1] == [NoteEvent(0.03, True, DRUM_PROGRAM, 1, 38)]
+    with pytest.raises(ValueError):
+        tm.detokenize_list_batches([row[None]], [0.0, 1.0])
+
+
+def test_multichannel_task_and_program_groups():
+    tm = TaskManager("mc13_full_plus_256")
+    assert tm.num_decoding_channels == 13 == len(MC13_GROUPS) and tm.max_note_token_length == 256
+    assert tm.channel_of_program(0) == 0 and tm.channel_of_program(33) == 4 and tm.channel_of_program(128) == 12
+    assert tm.channel_of_program(129) == 11
+    with pytest.raises(ValueError):
+        TaskManager("nope")
+    c = tm.codec
+    toks = np.zeros((1, 13, 16), dtype=np.int32)
+    for ch, prog in ((0, 0), (4, 33)):
+        toks[0, ch, :7] = [c.encode(Event("tie", 0)), c.encode(Event("shift", 10)), c.encode(Event("velocity", 1)),
+                           c.encode(Event("program", prog)), c.encode(Event("pitch", 50 + ch)), c.encode(Event("shift", 10)), EOS]
+    notes = tm.tokens_to_notes([toks], [0.0], end_sec=1.0)
+    assert [(n.program, n.pitch, n.onset, n.offset) for n in notes] == [(0, 50, 0.1, 1.0), (33, 54, 0.1, 1.0)]
+
+
+def test_midi_roundtrip(tmp_path):
+    notes = [Note(0.1, 0.5, False, 0, 60), Note(0.3, 2.5, False, 40, 64), Note(1.0, 1.01, True, DRUM_PROGRAM, 36),
+             Note(2.5, 3.0, False, 0, 60)]
+    data = notes_to_midi_bytes(notes)
+    assert data[:4] == b"MThd" and data.count(b"MTrk") == 4            # tempo + 3 programs
+    back = read_midi_notes(data)
+    assert len(back) == len(notes)
+    for a, b in zip(back, sorted(notes)):
+        assert (a.is_drum, a.program, a.pitch) == (b.is_drum, b.program, b.pitch)
+        assert abs(a.onset - b.onset) < 2e-3 and abs(a.offset - b.offset) < 2e-3
+    p = write_midi(notes, str(tmp_path / "x.mid"))
+    assert open(p, "rb").read() == data
+
+
+def test_slice_padded_array_and_wav_ingest(tmp_path):
+    x = np.arange(70000, dtype=np.float32)
+    s = slice_padded_array(x, 32767)
+    assert s.shape == (3, 1, 32767) and s[2, 0, 70000 - 2 * 32767 - 1] == 69999 and s[2, 0, 70000 - 2 * 32767] == 0
+    assert slice_padded_array(np.zeros(0, np.float32), 32767).shape == (1, 1, 32767)
+    assert slice_padded_array(np.zeros(32767, np.float32), 32767).shape == (1, 1, 32767)
+    path = str(tmp_path / "t.wav")
+    t = np.arange(44100) / 44100.0
+    stereo = np.stack([np.sin(2 * np.pi * 440 * t), np.sin(2 * np.pi * 440 * t)], 1)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100)
+        w.writeframes((stereo * 32767).astype("<i2").tobytes())
+    y, sr = load_wav(path)
+    assert sr == 44100 and y.shape == (44100,) and abs(np.abs(y).max() - 1.0) < 1e-3
+    z = resample(y, sr, 16000)
+    assert z.shape == (16000,) and z.dtype == np.float32
+    k = np.fft.rfft(z[:16000]).__abs__().argmax()
+    assert k == 440
+
+
+class _FakeModel:
+    """Stands in for YourMT3 on the CPU: returns the token arrays a perfect model would emit."""
+    def __init__(self, cfg, rows):
+        self.cfg, self.rows, self.calls = cfg, rows, []
+
+    def inference_file(self, bsz, segments, max_token_length=None):
+        self.calls.append((bsz, tuple(segments.shape), max_token_length))
+        return [self.rows[i:i + bsz] for i in range(0, self.rows.shape[0], bsz)]
+
+
+def test_transcribe_flow_writes_the_expected_midi(tmp_path):
+    cfg = YMT3Config()
+    tm = TaskManager()
+    notes = [Note(0.5, 1.0, False, 0, 60), Note(1.5, 3.0, False, 0, 64), Note(2.5, 2.51, True, DRUM_PROGRAM, 36)]
+    toks = _tokenize(tm, notes, 2, 1024)[:, None, :]
+    model = _FakeModel(cfg, toks)
+    audio = np.zeros(int(3.5 * 16000), dtype=np.float32)
+    path, got = transcribe(model, audio, task_manager=tm, bsz=1, output_dir=str(tmp_path), return_notes=True)
+    assert model.calls == [(1, (2, 1, 32767), 1024)]
+    assert os.path.basename(path) == "audio.mid" and len(got) == 3
+    back = read_midi_notes(open(path, "rb").read())
+    assert [(n.program, n.pitch) for n in back] == [(0, 60), (0, 64), (DRUM_PROGRAM, 36)]
+    assert abs(back[1].onset - 1.5) < 6e-3 and abs(back[1].offset - 3.0) < 6e-3
+    with pytest.raises(ValueError):
+        transcribe(model, audio, task_manager=TaskManager("mc13_full_plus_256"))
