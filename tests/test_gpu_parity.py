@@ -251,6 +251,26 @@ def test_transcribe_writes_a_midi_file(small, tmp_path):
     assert len(read_midi_notes(data)) == len(notes)       # random weights: any notes, but a well-formed file
 
 
+def test_moe_decoder_ffn_matches_oracle():
+    """a11 (build-defined spec, parity unpinned w.r.t. the reference): router -> top-2 -> expert FFNs -> gated sum."""
+    from yourmt3_amd.config import FFN_MOE
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=32, dec_ffn=FFN_MOE)
+    m = _model(cfg, max_batch=4)
+    assert "dec.0.router" in m.weights and m.weights["dec.0.wi"].shape == (8 * 2048, 512)
+    a = O.synthetic_audio(3, cfg)
+    _, enc = O.encode(a, m.weights, cfg, True)
+    n = 20
+    ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, n, True, return_logits=True)
+    got_t, got_l = m.decode(enc.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
+    d = (got_l.cpu() - ref_l).abs()
+    assert d.max().item() < 0.06 and d.mean().item() < 6e-3
+    safe = _margin(ref_l) >= TAU
+    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+    e = enc.bfloat16().cuda()
+    assert torch.equal(m.decode(e, n), m.decode(e, n))        # routing + grouped GEMM are reproducible
+    m.close()
+
+
 def test_bad_arguments_raise(small):
     from yourmt3_amd._lib import YMT3Error
     e = torch.zeros(1, SMALL.n_frames, SMALL.d_model, dtype=torch.bfloat16).cuda()

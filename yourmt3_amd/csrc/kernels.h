@@ -107,3 +107,23 @@ int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream);
 // all rows: h[r] = embed[pad] (+ chan_embed), finished = 0; a.shared[0..n_chains) reset
 int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int step0, int32_t* tokens_out, const int32_t* forced,
                        float* logits_out, hipStream_t stream);
+
+// ---------------------------------------------------------------- MoE decoder FFN (moe.hip)
+struct MoeArgs {
+    float* h;                   // [R][d_model] fp32 residual stream (read by router, updated by combine)
+    const float* gain;          // [d_model]
+    float* ssq; int ssq_stride; // carried sum(h^2) partials
+    const bf16_t* router;       // [E][d_model]
+    const bf16_t* wi;           // [E][d_ff][d_model]
+    const bf16_t* wo;           // [E][d_model][d_ff]
+    bf16_t* xn;                 // [R][d_model] normed rows (bf16)
+    int* sel; float* gate;      // [R][2] chosen experts and their gates
+    int* pair_rank; int* pair_row; float* pair_gate; int* row_pair;   // [2R] pair tables (expert-sorted order q)
+    int* item_expert; int* item_pair0; int* item_count; int* n_items; // work items of <= 16 pairs
+    bf16_t* hidden;             // [2R][d_ff]
+    float* y;                   // [2R][d_model] gate-scaled expert outputs
+    int row0, R, E, top_k, d_model, d_ff;
+    float eps;
+};
+int init_moe_kernels();
+int launch_moe_stage(int stage, const MoeArgs& a, hipStream_t stream);

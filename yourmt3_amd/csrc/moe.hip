@@ -1,0 +1,232 @@
+// a11 of SURVEY.md section 8: mixture-of-experts decoder FFN (E experts, top-k = 2), decode-time form.
+// The reference tree has no implementation and the container no oracle (SURVEY section 2.2 star-9): the
+// arithmetic below is this build's own spec, restated on the CPU in oracle/ymt3_oracle.py::moe_ffn
+// ("parity unpinned" with respect to the reference):
+//     xn      = R( rmsnorm(h) * gain )                         bf16, shared by router and experts
+//     logits  = xn . router^T                                  fp32, E values per row
+//     (e0,e1) = the two largest logits, ties to the lower expert id; gates = softmax(l[e0], l[e1])
+//     y_j     = R( relu(xn . wi[e_j]^T) ) . wo[e_j]^T           dense ReLU FFN of expert e_j
+//     h      += g0*y_0 + g1*y_1                                 fp32, slot order fixed
+//
+// Four kernels, no float atomics, every reduction in a fixed order (bitwise reproducible):
+//   moe_router_kernel   one wave per row: norm from the carried sum(h^2) partials, router dots, top-2, gates
+//   moe_plan_kernel     one workgroup: stable counting sort of the 2R (row, slot) pairs by expert ->
+//                       pair tables + (expert, first pair, count) work items of <= 16 pairs
+//   moe_gemm_kernel     grouped skinny GEMM over the work items: same coalesced-load / wave-private-LDS-strip /
+//                       8-way split-K structure as dec_gemm_kernel, rows gathered through the pair table
+//   moe_combine_kernel  one wave per row: h += y[pair0] + y[pair1]; sum(h^2) for the next norm
+// Expert weights are replicated on every GPU (8 x 2 x 2 MB per layer): the path stays pure data-parallel,
+// no all-to-all.  bf16 MFMA; the fp8 variant BASELINE configs[4] names is not built yet.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int E_MAX = 16;
+
+__global__ __launch_bounds__(512) void moe_router_kernel(MoeArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = a.row0 + blockIdx.x * 8 + wave;
+    if (r >= a.row0 + a.R) return;
+    constexpr int D = 512;
+    float ss = 0.f;
+    if (lane < SSQ_TILES) ss = a.ssq[(size_t)lane * a.ssq_stride + r];
+    // fixed order: pairwise tree over the 32 partials (lanes >= 32 contribute 0)
+    ss = wave_sum(ss);
+    const float sc = rsqrtf(ss / (float)D + a.eps);
+    const float4* x = reinterpret_cast<const float4*>(a.h + (size_t)r * D);
+    const float4* g = reinterpret_cast<const float4*>(a.gain);
+    float xn[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 v = x[lane + 64 * i], gg = g[lane + 64 * i];
+        const bf16_t b0 = f2bf(v.x * sc * gg.x), b1 = f2bf(v.y * sc * gg.y), b2 = f2bf(v.z * sc * gg.z), b3 = f2bf(v.w * sc * gg.w);
+        *reinterpret_cast<uint2*>(a.xn + (size_t)r * D + (lane + 64 * i) * 4) =
+            make_uint2((uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)b2 | ((uint32_t)b3 << 16));
+        xn[4 * i] = bf2f(b0); xn[4 * i + 1] = bf2f(b1); xn[4 * i + 2] = bf2f(b2); xn[4 * i + 3] = bf2f(b3);
+    }
+    float best = -3.4e38f, second = -3.4e38f;
+    int e0 = 0, e1 = 0;
+    for (int e = 0; e < a.E; ++e) {
+        const bf16_t* w = a.router + (size_t)e * D;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint2 wv = *reinterpret_cast<const uint2*>(w + (lane + 64 * i) * 4);
+            s = fmaf(xn[4 * i], __uint_as_float(wv.x << 16), s);
+            s = fmaf(xn[4 * i + 1], __uint_as_float(wv.x & 0xffff0000u), s);
+            s = fmaf(xn[4 * i + 2], __uint_as_float(wv.y << 16), s);
+            s = fmaf(xn[4 * i + 3], __uint_as_float(wv.y & 0xffff0000u), s);
+        }
+        s = wave_sum(s);
+        if (s > best) { second = best; e1 = e0; best = s; e0 = e; }
+        else if (s > second) { second = s; e1 = e; }
+    }
+    if (lane == 0) {
+        const float t = __expf(second - best);
+        a.sel[2 * r] = e0; a.sel[2 * r + 1] = e1;
+        a.gate[2 * r] = 1.0f / (1.0f + t); a.gate[2 * r + 1] = t / (1.0f + t);
+    }
+}
+
+// stable counting sort of pairs (row, slot) by expert; order inside an expert: (row, slot) ascending
+__global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs a) {
+    __shared__ int cnt[E_MAX], off[E_MAX + 1], wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = 2 * a.R;                                     // pairs, p = 2*(r - row0) + slot
+    for (int e = 0; e < a.E; ++e) {
+        int run = 0;                                           // pairs of expert e seen in earlier chunks
+        for (int base = 0; base < P; base += 1024) {
+            const int p = base + tid;
+            const int flag = (p < P && a.sel[2 * a.row0 + p] == e) ? 1 : 0;
+            // block exclusive scan of flag
+            int v = flag;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+            if (lane == 63) wsum[wave] = v;
+            __syncthreads();
+            int wbase = 0, total = 0;
+            for (int w = 0; w < 16; ++w) { if (w < wave) wbase += wsum[w]; total += wsum[w]; }
+            if (flag) a.pair_rank[a.row0 * 2 + p] = run + wbase + v - 1;      // rank inside its expert
+            run += total;
+            __syncthreads();
+        }
+        if (tid == 0) cnt[e] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0, items = 0;
+        for (int e = 0; e < a.E; ++e) {
+            off[e] = o;
+            for (int c = 0; c < cnt[e]; c += 16) {
+                a.item_expert[items] = e; a.item_pair0[items] = o + c; a.item_count[items] = min(16, cnt[e] - c);
+                ++items;
+            }
+            o += cnt[e];
+        }
+        off[a.E] = o;
+        *a.n_items = items;
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += 1024) {
+        const int e = a.sel[2 * a.row0 + p];
+        const int q = off[e] + a.pair_rank[a.row0 * 2 + p];    // position in the expert-sorted order
+        a.pair_row[q] = a.row0 + (p >> 1);
+        a.pair_gate[q] = a.gate[2 * a.row0 + p];
+        a.row_pair[2 * a.row0 + p] = q;
+    }
+}
+
+// STAGE 0: hidden[q] = R(relu(xn[pair_row[q]] . wi[e]^T))   (K = d_model, N = d_ff)
+// STAGE 1: y[q]      = gate[q] * (hidden[q] . wo[e]^T)      (K = d_ff,    N = d_model)
+template <int STAGE, int K>
+__global__ __launch_bounds__(512) void moe_gemm_kernel(MoeArgs a) {
+    constexpr int KW = K / 8, KS = KW / 32, PITCH = KW * 2 + 16, STRIP = 16 * PITCH;
+    constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);               // [8][16][16]
+    char* strips = smem + 8 * 16 * 16 * 4;
+
+    const int n_nt = (STAGE == 0 ? a.d_ff : a.d_model) / 16;
+    const int item = blockIdx.x / n_nt, nt = blockIdx.x % n_nt;
+    if (item >= *a.n_items) return;
+    const int e = a.item_expert[item], q0 = a.item_pair0[item], cnt = a.item_count[item];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int n0 = nt * 16, N = STAGE == 0 ? a.d_ff : a.d_model;
+    const bf16_t* W = (STAGE == 0 ? a.wi : a.wo) + (size_t)e * N * K;
+
+    char* sA = strips + wave * 2 * STRIP;
+    char* sW = sA + STRIP;
+    u32x4 wv[NI], av[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = i * RPI + lane / LPR, ch = lane % LPR;
+        wv[i] = *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + row) * K + wave * KW + ch * 8);
+        const int q = q0 + (row < cnt ? row : cnt - 1);
+        const bf16_t* arow = STAGE == 0 ? a.xn + (size_t)a.pair_row[q] * K : a.hidden + (size_t)q * K;
+        av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int o = (i * RPI + lane / LPR) * PITCH + (lane % LPR) * 16;
+        *reinterpret_cast<u32x4*>(sW + o) = wv[i];
+        *reinterpret_cast<u32x4*>(sA + o) = av[i];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int o = li * PITCH + (ks * 32 + g * 8) * 2;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(sW + o),
+                                                      *reinterpret_cast<const bf16x8*>(sA + o), acc, 0, 0, 0);
+    }
+    *reinterpret_cast<float4*>(red + ((wave * 16 + li) * 16 + g * 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (tid >= 128) return;
+    const int mr = tid >> 3, nq = (tid & 7) * 2;
+    float2 s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+        const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * 16 + nq));
+        s.x += t.x; s.y += t.y;
+    }
+    if (mr >= cnt) return;
+    const int q = q0 + mr;
+    if constexpr (STAGE == 0) {
+        *reinterpret_cast<uint32_t*>(a.hidden + (size_t)q * a.d_ff + n0 + nq) = pack_bf16x2(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f));
+    } else {
+        const float gt = a.pair_gate[q];
+        *reinterpret_cast<float2*>(a.y + (size_t)q * a.d_model + n0 + nq) = make_float2(gt * s.x, gt * s.y);
+    }
+}
+
+__global__ __launch_bounds__(512) void moe_combine_kernel(MoeArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = a.row0 + blockIdx.x * 8 + wave;
+    if (r >= a.row0 + a.R) return;
+    constexpr int D = 512;
+    const float4* y0 = reinterpret_cast<const float4*>(a.y + (size_t)a.row_pair[2 * r] * D);
+    const float4* y1 = reinterpret_cast<const float4*>(a.y + (size_t)a.row_pair[2 * r + 1] * D);
+    float4* h = reinterpret_cast<float4*>(a.h + (size_t)r * D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 u = y0[lane + 64 * i], v = y1[lane + 64 * i];
+        float4 o = h[lane + 64 * i];
+        o.x += u.x + v.x; o.y += u.y + v.y; o.z += u.z + v.z; o.w += u.w + v.w;
+        h[lane + 64 * i] = o;
+        q += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+    }
+    q = wave_sum(q);
+    if (lane < SSQ_TILES) a.ssq[(size_t)lane * a.ssq_stride + r] = lane == 0 ? q : 0.f;
+}
+
+template <int STAGE, int K>
+constexpr size_t moe_lds() { return (size_t)8 * 16 * 16 * 4 + (size_t)8 * 2 * 16 * (K / 8 * 2 + 16); }
+
+}  // namespace
+
+int init_moe_kernels() {
+    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_kernel<0, 512>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_lds<0, 512>());
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_kernel<1, 2048>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_lds<1, 2048>());
+    return (e0 == hipSuccess && e1 == hipSuccess) ? 0 : -2;
+}
+
+// stage: 0 router, 1 plan, 2 expert wi, 3 expert wo, 4 combine
+int launch_moe_stage(int stage, const MoeArgs& a, hipStream_t stream) {
+    if (a.R <= 0) return 0;
+    if (a.d_model != 512 || a.d_ff != 2048 || a.E > E_MAX || a.top_k != 2) return -1;
+    const int max_items = (2 * a.R + 15) / 16 + a.E;
+    switch (stage) {
+        case 0: moe_router_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a); break;
+        case 1: moe_plan_kernel<<<1, 1024, 0, stream>>>(a); break;
+        case 2: moe_gemm_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_lds<0, 512>(), stream>>>(a); break;
+        case 3: moe_gemm_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_lds<1, 2048>(), stream>>>(a); break;
+        case 4: moe_combine_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a); break;
+        default: return -1;
+    }
+    return 0;
+}

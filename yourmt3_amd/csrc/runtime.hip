@@ -70,6 +70,7 @@ struct ymt3_ctx {
     bf16_t *dq = nullptr, *dattn = nullptr, *dff = nullptr;
     float* logits = nullptr;
     float* ssq = nullptr;               // [SSQ_TILES][maxR]
+    MoeArgs moe{};                      // scratch pointers of the MoE FFN (dec_ffn == YMT3_FFN_MOE)
     int* finished = nullptr;
     DecodeShared* shared = nullptr;     // [MAX_CHAINS] per-chain loop state
     hipStream_t cap_stream = nullptr;
@@ -195,7 +196,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (k.d_model != 16 * SSQ_TILES) FAIL(YMT3_ERR_UNSUPPORTED, "d_model must be 512 (got %d)", k.d_model);
     if (k.n_heads * k.d_kv != 512) FAIL(YMT3_ERR_UNSUPPORTED, "n_heads*d_kv must be 512");
     if (k.encoder_type != YMT3_ENC_T5) FAIL(YMT3_ERR_UNSUPPORTED, "encoder_type %d not built yet", k.encoder_type);
-    if (k.dec_ffn != YMT3_FFN_DENSE) FAIL(YMT3_ERR_UNSUPPORTED, "dec_ffn %d not built yet", k.dec_ffn);
+    if (k.dec_ffn == YMT3_FFN_MOE && (k.moe_top_k != 2 || k.n_experts < 2 || k.n_experts > 16 || k.d_ff != 2048))
+        FAIL(YMT3_ERR_UNSUPPORTED, "MoE FFN needs top_k = 2, 2..16 experts, d_ff = 2048");
     if (k.max_batch <= 0 || k.n_channels <= 0 || k.max_decode_len <= 0) FAIL(YMT3_ERR_ARG, "bad max_batch / n_channels / max_decode_len");
     c->T = 1 + k.segment_samples / k.hop;
     c->inner = k.n_heads * k.d_kv;
@@ -207,7 +209,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     HIP_TRY(hipSetDevice(c->device));
     int rc = parse_blob(c, blob, nbytes);
     if (rc) return rc;
-    if (init_enc_attn_kernels() || init_decode_kernels()) FAIL(YMT3_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+    if (init_enc_attn_kernels() || init_decode_kernels() || init_moe_kernels()) FAIL(YMT3_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
 
     // front-end tables (built by yourmt3_amd/tables.py, carried in the blob)
     const int nfft = k.n_fft;
@@ -253,6 +255,17 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->logits, R * k.vocab * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->finished, R * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->ssq, (size_t)SSQ_TILES * R * 4)) return YMT3_ERR_HIP;
+    if (k.dec_ffn == YMT3_FFN_MOE) {
+        MoeArgs& m = c->moe;
+        const size_t P = 2 * R, items = P / 16 + k.n_experts + 1;
+        if (dev_alloc(c, (void**)&m.xn, R * d * 2) || dev_alloc(c, (void**)&m.sel, P * 4) || dev_alloc(c, (void**)&m.gate, P * 4) ||
+            dev_alloc(c, (void**)&m.pair_rank, P * 4) || dev_alloc(c, (void**)&m.pair_row, P * 4) || dev_alloc(c, (void**)&m.pair_gate, P * 4) ||
+            dev_alloc(c, (void**)&m.row_pair, P * 4) || dev_alloc(c, (void**)&m.item_expert, items * 4) ||
+            dev_alloc(c, (void**)&m.item_pair0, items * 4) || dev_alloc(c, (void**)&m.item_count, items * 4) ||
+            dev_alloc(c, (void**)&m.n_items, 16) || dev_alloc(c, (void**)&m.hidden, P * k.d_ff * 2) || dev_alloc(c, (void**)&m.y, P * d * 4))
+            return YMT3_ERR_HIP;
+        m.E = k.n_experts; m.top_k = k.moe_top_k; m.d_model = d; m.d_ff = k.d_ff; m.eps = k.ln_eps;
+    }
     if (dev_alloc(c, (void**)&c->shared, 8 * sizeof(DecodeShared))) return YMT3_ERR_HIP;
     HIP_TRY(hipMemset(c->shared, 0, 8 * sizeof(DecodeShared)));
     HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
@@ -371,7 +384,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     bf16_t* w;
     float* f;
     // every weight of the step up front
-    struct LayerW { float *ln1, *ln2, *ln3; bf16_t *wqkv, *wo, *wq_c, *wo_c, *wi, *wo2; };
+    struct LayerW { float *ln1, *ln2, *ln3; bf16_t *wqkv, *wo, *wq_c, *wo_c, *wi, *wo2, *router; };
     std::vector<LayerW> LW(k.n_dec_layers);
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const std::string p = "dec." + std::to_string(l) + ".";
@@ -382,8 +395,11 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         GET(h, p + "wo", 1u, &LW[l].wo, (size_t)d * inner);
         GET(h, p + "wq_c", 1u, &LW[l].wq_c, (size_t)inner * d);
         GET(h, p + "wo_c", 1u, &LW[l].wo_c, (size_t)d * inner);
-        GET(h, p + "wi", 1u, &LW[l].wi, (size_t)k.d_ff * d);
-        GET(h, p + "wo2", 1u, &LW[l].wo2, (size_t)d * k.d_ff);
+        const size_t ne = k.dec_ffn == YMT3_FFN_MOE ? (size_t)k.n_experts : 1;
+        GET(h, p + "wi", 1u, &LW[l].wi, ne * k.d_ff * d);
+        GET(h, p + "wo2", 1u, &LW[l].wo2, ne * d * k.d_ff);
+        LW[l].router = nullptr;
+        if (k.dec_ffn == YMT3_FFN_MOE) GET(h, p + "router", 1u, &LW[l].router, (size_t)k.n_experts * d);
     }
     bf16_t* lm_head;
     GET(h, "dec.lm_head", 1u, &lm_head, (size_t)k.vocab * d);
@@ -411,10 +427,18 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         a.a_bf16 = h->dattn; a.W = W.wo_c; a.N = d; a.K = inner;
         PLAUNCH(PC_CROSS_O, launch_dec_gemm(DG_RESID, a, s));
         // feed-forward block
-        a.gain = W.ln3; a.W = W.wi; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
-        PLAUNCH(PC_FFN_WI, launch_dec_gemm(DG_NORM_BF16_RELU, a, s));
-        a.a_bf16 = h->dff; a.W = W.wo2; a.N = d; a.K = k.d_ff;
-        PLAUNCH(PC_FFN_WO, launch_dec_gemm(DG_RESID, a, s));
+        if (k.dec_ffn == YMT3_FFN_MOE) {
+            MoeArgs mo = h->moe;
+            mo.h = h->h_dec; mo.gain = W.ln3; mo.ssq = h->ssq; mo.ssq_stride = h->maxR;
+            mo.router = W.router; mo.wi = W.wi; mo.wo = W.wo2; mo.row0 = row0; mo.R = R;
+            { ProfScope _ps(h, PC_FFN_WI, s); LAUNCH(launch_moe_stage(0, mo, s)); LAUNCH(launch_moe_stage(1, mo, s)); LAUNCH(launch_moe_stage(2, mo, s)); }
+            { ProfScope _ps(h, PC_FFN_WO, s); LAUNCH(launch_moe_stage(3, mo, s)); LAUNCH(launch_moe_stage(4, mo, s)); }
+        } else {
+            a.gain = W.ln3; a.W = W.wi; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
+            PLAUNCH(PC_FFN_WI, launch_dec_gemm(DG_NORM_BF16_RELU, a, s));
+            a.a_bf16 = h->dff; a.W = W.wo2; a.N = d; a.K = k.d_ff;
+            PLAUNCH(PC_FFN_WO, launch_dec_gemm(DG_RESID, a, s));
+        }
     }
     DecGemmArgs a{};
     a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
@@ -445,7 +469,7 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
     GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&a.embed), (size_t)k.vocab * d);
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&a.chan_embed), (size_t)k.n_channels * d);
     // chains: contiguous, near-equal row ranges
-    int n_chains = (!h->use_graph || prof_stride > 0) ? 1 : h->n_chains;
+    int n_chains = (!h->use_graph || prof_stride > 0 || k.dec_ffn == YMT3_FFN_MOE) ? 1 : h->n_chains;   // MoE pair tables are per handle
     if (n_chains > R) n_chains = R;
     LAUNCH(launch_decode_init(a, n_chains, n_steps, h->prof_step0, tokens, forced, logits_out, s));
     int row0[9];
