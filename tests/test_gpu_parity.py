@@ -271,6 +271,31 @@ def test_moe_decoder_ffn_matches_oracle():
     m.close()
 
 
+def test_perceiver_latent_encoder_matches_oracle():
+    """a9 (build-defined spec, parity unpinned w.r.t. the reference): latent array cross-attends to the frames,
+    then latent self-attention blocks; decoder unchanged."""
+    from yourmt3_amd.config import ENC_PERCEIVER_TF
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=32, encoder_type=ENC_PERCEIVER_TF, n_latents=64)
+    m = _model(cfg, max_batch=4)
+    a = O.synthetic_audio(3, cfg)
+    mel_ref, enc_ref = O.encode(a, m.weights, cfg, True)
+    enc = m.encode(m.logmel(a.cuda()))
+    d = (enc.float().cpu() - enc_ref).abs()
+    assert d.max().item() <= 0.0625 and d.mean().item() <= 4e-3
+    t5 = O.encoder_t5(O.input_projection(mel_ref, m.weights, True), m.weights, cfg, True)
+    assert (enc_ref - t5).abs().mean().item() > 0.3                 # it really is a different encoder
+    n = 16
+    ref_t, ref_l = O.greedy_decode(enc_ref, m.weights, cfg, n, True, return_logits=True)
+    got_t, got_l = m.decode(enc_ref.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
+    assert (got_l.cpu() - ref_l).abs().max().item() < 0.06
+    safe = _margin(ref_l) >= TAU
+    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+    m.close()
+    from yourmt3_amd._lib import YMT3Error
+    with pytest.raises(YMT3Error):
+        _model(cfg.with_(n_latents=32))                             # latent length is tied to the frame count
+
+
 def test_bad_arguments_raise(small):
     from yourmt3_amd._lib import YMT3Error
     e = torch.zeros(1, SMALL.n_frames, SMALL.d_model, dtype=torch.bfloat16).cuda()

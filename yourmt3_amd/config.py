@@ -51,7 +51,7 @@ class YMT3Config:
     pad_id: int = PAD_ID
     # --- architecture variants ---
     encoder_type: int = ENC_T5        # ENC_PERCEIVER_TF for config 3
-    n_latents: int = 24               # Perceiver-TF latent array size per frame
+    n_latents: int = 256              # Perceiver latent array length (= decoder cross-attention length; must equal n_frames)
     dec_ffn: int = FFN_DENSE          # FFN_MOE for config 5
     n_experts: int = 8
     moe_top_k: int = 2
@@ -115,7 +115,7 @@ def baseline_config(i: int) -> YMT3Config:
     if i == 1:      # MT3 base (T5-small) bf16, batch 64, 1024-token decoder
         return base.with_(eos_id=-1)
     if i == 2:      # Perceiver-TF encoder + T5 decoder, batch 256
-        return base.with_(encoder_type=ENC_PERCEIVER_TF, eos_id=-1)
+        return base.with_(encoder_type=ENC_PERCEIVER_TF, n_latents=base.n_frames, eos_id=-1)
     if i == 3:      # 13-channel multi-track decoder, 256 tokens per channel
         return base.with_(n_channels=13, max_decode_len=256, eos_id=-1)
     if i == 4:      # MoE decoder FFN (8 experts)

@@ -20,9 +20,13 @@ namespace {
 constexpr int DKV = 64;
 constexpr int ROWB = 144;   // LDS row pitch in bytes (128 + 16 pad: spreads rows over the banks)
 
+// q rows: q + (b*T + t) * ldq + h*64;  k / v rows: k|v + (b*T + t) * ldkv + h*64.  The T5 encoder passes one fused
+// qkv buffer (k = qkv + inner, v = qkv + 2*inner, ldq = ldkv = 3*inner); the latent cross-attention (a9) passes
+// the latent queries and the frame K/V as separate buffers.
 template <int T>
-__global__ __launch_bounds__(256) void enc_attn_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_off,
-                                                       bf16_t* __restrict__ out, int H) {
+__global__ __launch_bounds__(256) void enc_attn_kernel(const bf16_t* __restrict__ qp, int ldq, const bf16_t* __restrict__ kp,
+                                                       const bf16_t* __restrict__ vp, int ldkv,
+                                                       const float* __restrict__ bias_off, bf16_t* __restrict__ out, int H) {
     constexpr int NT = T / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
@@ -31,14 +35,14 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16_t* __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int inner = H * DKV, ld = 3 * inner;
-    const bf16_t* base = qkv + (size_t)b * T * ld + h * DKV;
+    const int inner = H * DKV;
+    const size_t kvoff = (size_t)b * T * ldkv + h * DKV;
 
     for (int idx = tid; idx < T * 8; idx += 256) {
         const int row = idx >> 3, ch = idx & 7;
-        const bf16_t* src = base + (size_t)row * ld + ch * 8;
-        *reinterpret_cast<uint4*>(sK + row * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(src + inner);
-        *reinterpret_cast<uint4*>(sV + row * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(src + 2 * inner);
+        const size_t o = kvoff + (size_t)row * ldkv + ch * 8;
+        *reinterpret_cast<uint4*>(sK + row * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(kp + o);
+        *reinterpret_cast<uint4*>(sV + row * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(vp + o);
     }
     for (int i = tid; i < 2 * T - 1; i += 256) sB[i] = bias_off[(size_t)h * (2 * T - 1) + i];
 
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16_t* __restrict_
     bf16x8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-        qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + (size_t)q * ld + ks * 32 + g * 8));
+        qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + ((size_t)b * T + q) * ldq + h * DKV + ks * 32 + g * 8));
     __syncthreads();
 
     // S^T tiles: lane -> query q, keys kt*16 + 4g + r
@@ -119,29 +123,39 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16_t* __restrict_
 }
 
 template <int T>
-int launch_t(const bf16_t* qkv, const float* bias_off, bf16_t* out, int B, int H, hipStream_t stream) {
+int launch_t(const bf16_t* q, int ldq, const bf16_t* k, const bf16_t* v, int ldkv, const float* bias_off, bf16_t* out, int B,
+             int H, hipStream_t stream) {
     const size_t lds = (size_t)2 * T * ROWB + (2 * T - 1) * sizeof(float) + 16;
-    if (qkv == nullptr)     // attribute-only call from init_enc_attn_kernels()
+    if (q == nullptr)       // attribute-only call from init_enc_attn_kernels()
         return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -2;
-    enc_attn_kernel<T><<<dim3(T / 64, H, B), 256, lds, stream>>>(qkv, bias_off, out, H);
+    enc_attn_kernel<T><<<dim3(T / 64, H, B), 256, lds, stream>>>(q, ldq, k, v, ldkv, bias_off, out, H);
     return 0;
 }
 
 }  // namespace
 
 int init_enc_attn_kernels() {
-    return launch_t<64>(nullptr, nullptr, nullptr, 1, 1, nullptr) | launch_t<128>(nullptr, nullptr, nullptr, 1, 1, nullptr) |
-           launch_t<256>(nullptr, nullptr, nullptr, 1, 1, nullptr) | launch_t<512>(nullptr, nullptr, nullptr, 1, 1, nullptr);
+    return launch_t<64>(nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, 1, nullptr) |
+           launch_t<128>(nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, 1, nullptr) |
+           launch_t<256>(nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, 1, nullptr) |
+           launch_t<512>(nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, 1, nullptr);
+}
+
+int launch_enc_attention_qkv(const bf16_t* q, int ldq, const bf16_t* k, const bf16_t* v, int ldkv, const float* bias_off,
+                             bf16_t* out, int B, int T, int H, hipStream_t stream) {
+    if (B <= 0) return 0;
+    if ((ldq % 8) || (ldkv % 8)) return -1;
+    switch (T) {
+        case 64: return launch_t<64>(q, ldq, k, v, ldkv, bias_off, out, B, H, stream);
+        case 128: return launch_t<128>(q, ldq, k, v, ldkv, bias_off, out, B, H, stream);
+        case 256: return launch_t<256>(q, ldq, k, v, ldkv, bias_off, out, B, H, stream);
+        case 512: return launch_t<512>(q, ldq, k, v, ldkv, bias_off, out, B, H, stream);
+        default: return -1;
+    }
 }
 
 int launch_enc_attention(const bf16_t* qkv, const float* bias_off, bf16_t* out, int B, int T, int H, hipStream_t stream) {
-    if (B <= 0) return 0;
-    switch (T) {
-        case 64: return launch_t<64>(qkv, bias_off, out, B, H, stream);
-        case 128: return launch_t<128>(qkv, bias_off, out, B, H, stream);
-        case 256: return launch_t<256>(qkv, bias_off, out, B, H, stream);
-        case 512: return launch_t<512>(qkv, bias_off, out, B, H, stream);
-        default: return -1;
-    }
+    const int inner = H * DKV;
+    return launch_enc_attention_qkv(qkv, 3 * inner, qkv + inner, qkv + 2 * inner, 3 * inner, bias_off, out, B, T, H, stream);
 }

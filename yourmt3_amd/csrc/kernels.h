@@ -38,10 +38,15 @@ int launch_gemm(int epilogue, const GemmArgs& a, hipStream_t stream);
 // out bf16 [M][d] = R(x * rsqrt(mean(x^2) + eps) * gain)
 int launch_rmsnorm(const float* x, const float* gain, bf16_t* out, int M, int d, float eps, hipStream_t stream);
 int launch_f32_to_bf16(const float* x, bf16_t* out, size_t n, hipStream_t stream);
+// out f32 [B][n] = src bf16 [n] repeated for every b (the latent array as the initial residual stream)
+int launch_broadcast_bf16(const bf16_t* src, float* out, int B, size_t n, hipStream_t stream);
 
 // ---------------------------------------------------------------- encoder attention (enc_attn.hip)
 // qkv bf16 [B*T][3*H*64] -> out bf16 [B*T][H*64]; bias_off f32 [H][2T-1] indexed by key - query + T-1
 int init_enc_attn_kernels();
+// general form: queries and keys/values from separate buffers (latent cross-attention, a9)
+int launch_enc_attention_qkv(const bf16_t* q, int ldq, const bf16_t* k, const bf16_t* v, int ldkv, const float* bias_off,
+                             bf16_t* out, int B, int T, int H, hipStream_t stream);
 int launch_enc_attention(const bf16_t* qkv, const float* bias_off, bf16_t* out, int B, int T, int H, hipStream_t stream);
 
 // ---------------------------------------------------------------- decoder step (decode.hip)

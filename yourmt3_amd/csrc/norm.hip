@@ -37,6 +37,14 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, 
     }
 }
 
+__global__ __launch_bounds__(256) void broadcast_kernel(const bf16_t* __restrict__ src, float* __restrict__ out, size_t n4, size_t total4) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const uint2 v = reinterpret_cast<const uint2*>(src)[i % n4];
+        reinterpret_cast<float4*>(out)[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                        __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+}
+
 }  // namespace
 
 int launch_rmsnorm(const float* x, const float* gain, bf16_t* out, int M, int d, float eps, hipStream_t stream) {
@@ -53,5 +61,15 @@ int launch_f32_to_bf16(const float* x, bf16_t* out, size_t n, hipStream_t stream
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     cast_kernel<<<(int)blocks, 256, 0, stream>>>(x, out, n4);
+    return 0;
+}
+
+int launch_broadcast_bf16(const bf16_t* src, float* out, int B, size_t n, hipStream_t stream) {
+    if (B <= 0 || n == 0) return 0;
+    if (n % 4) return -1;
+    const size_t total4 = (size_t)B * n / 4;
+    size_t blocks = (total4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    broadcast_kernel<<<(int)blocks, 256, 0, stream>>>(src, out, n / 4, total4);
     return 0;
 }

@@ -62,6 +62,7 @@ struct ymt3_ctx {
     bf16_t* mel_bf = nullptr;
     float* h_enc = nullptr;
     bf16_t *xn = nullptr, *qkv = nullptr, *attn = nullptr, *ff = nullptr, *enc_out = nullptr;
+    float* zero_bias = nullptr;         // [H][2T-1] zeros: the latent cross-attention has no position bias
     // decoder workspace
     bf16_t* wkv_all = nullptr;          // [n_dec*2*inner][d]
     bf16_t* ckv = nullptr;              // [n_dec*2][B][H][T][64]
@@ -195,7 +196,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (k.d_kv != 64) FAIL(YMT3_ERR_UNSUPPORTED, "d_kv must be 64 (got %d)", k.d_kv);
     if (k.d_model != 16 * SSQ_TILES) FAIL(YMT3_ERR_UNSUPPORTED, "d_model must be 512 (got %d)", k.d_model);
     if (k.n_heads * k.d_kv != 512) FAIL(YMT3_ERR_UNSUPPORTED, "n_heads*d_kv must be 512");
-    if (k.encoder_type != YMT3_ENC_T5) FAIL(YMT3_ERR_UNSUPPORTED, "encoder_type %d not built yet", k.encoder_type);
+    if (k.encoder_type != YMT3_ENC_T5 && k.encoder_type != YMT3_ENC_PERCEIVER_TF) FAIL(YMT3_ERR_UNSUPPORTED, "unknown encoder_type %d", k.encoder_type);
     if (k.dec_ffn == YMT3_FFN_MOE && (k.moe_top_k != 2 || k.n_experts < 2 || k.n_experts > 16 || k.d_ff != 2048))
         FAIL(YMT3_ERR_UNSUPPORTED, "MoE FFN needs top_k = 2, 2..16 experts, d_ff = 2048");
     if (k.max_batch <= 0 || k.n_channels <= 0 || k.max_decode_len <= 0) FAIL(YMT3_ERR_ARG, "bad max_batch / n_channels / max_decode_len");
@@ -235,6 +236,15 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->attn, BT * c->inner * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->ff, BT * k.d_ff * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->enc_out, BT * d * 2)) return YMT3_ERR_HIP;
+    if (k.encoder_type == YMT3_ENC_PERCEIVER_TF) {
+        if (k.n_latents != c->T) FAIL(YMT3_ERR_UNSUPPORTED, "n_latents (%d) must equal n_frames (%d) in this build", k.n_latents, c->T);
+        const size_t zb = (size_t)k.n_heads * (2 * c->T - 1) * 4;
+        if (dev_alloc(c, (void**)&c->zero_bias, zb)) return YMT3_ERR_HIP;
+        HIP_TRY(hipMemset(c->zero_bias, 0, zb));
+        const char* ptf_names[] = {"latents", "ca.ln_q", "ca.ln_kv", "ca.wq", "ca.wkv", "ca.wo", "ca.ln_ff", "ca.wi", "ca.wo2"};
+        for (const char* n : ptf_names)
+            if (!c->tensors.count(std::string("ptf.") + n)) FAIL(YMT3_ERR_BLOB, "missing ptf.%s", n);
+    }
 
     const int nd = k.n_dec_layers;
     const size_t wkv_elems = (size_t)2 * c->inner * d;
@@ -339,6 +349,31 @@ static int encode_impl(ymt3_handle h, const float* mel, int B, bf16_t* enc_out, 
         GET(h, "in_proj.b", 0u, &bias, (size_t)d);
         GemmArgs g{h->mel_bf, w, h->h_enc, bias, M, d, k.n_mels, k.n_mels, k.n_mels, d, 0, 0, 0};
         LAUNCH(launch_gemm(EPI_F32, g, s));
+    }
+    if (k.encoder_type == YMT3_ENC_PERCEIVER_TF) {
+        // a9: the learned latent array cross-attends ONCE to the projected frames (pre-norm on both sides, query
+        // residual, ReLU FFN); the enc.* blocks below then run as latent self-attention.  Oracle:
+        // oracle/perceiver_oracle.py::latent_cross_attention.
+        bf16_t* lat;
+        GET(h, "ptf.ca.ln_kv", 0u, &f, (size_t)d);
+        LAUNCH(launch_rmsnorm(h->h_enc, f, h->xn, M, d, k.ln_eps, s));
+        GET(h, "ptf.ca.wkv", 1u, &w, (size_t)2 * inner * d);
+        { GemmArgs g{h->xn, w, h->qkv, nullptr, M, 2 * inner, d, d, d, 2 * inner, 0, 0, 0}; LAUNCH(launch_gemm(EPI_BF16, g, s)); }
+        GET(h, "ptf.latents", 1u, &lat, (size_t)h->T * d);
+        LAUNCH(launch_broadcast_bf16(lat, h->h_enc, B, (size_t)h->T * d, s));      // z: the frames' stream is no longer needed
+        GET(h, "ptf.ca.ln_q", 0u, &f, (size_t)d);
+        LAUNCH(launch_rmsnorm(h->h_enc, f, h->xn, M, d, k.ln_eps, s));
+        GET(h, "ptf.ca.wq", 1u, &w, (size_t)inner * d);
+        { GemmArgs g{h->xn, w, h->attn, nullptr, M, inner, d, d, d, inner, 0, 0, 0}; LAUNCH(launch_gemm(EPI_BF16, g, s)); }
+        LAUNCH(launch_enc_attention_qkv(h->attn, inner, h->qkv, h->qkv + inner, 2 * inner, h->zero_bias, h->ff, B, h->T, k.n_heads, s));
+        GET(h, "ptf.ca.wo", 1u, &w, (size_t)d * inner);
+        { GemmArgs g{h->ff, w, h->h_enc, nullptr, M, d, inner, inner, inner, d, 0, 0, 0}; LAUNCH(launch_gemm(EPI_RESID, g, s)); }
+        GET(h, "ptf.ca.ln_ff", 0u, &f, (size_t)d);
+        LAUNCH(launch_rmsnorm(h->h_enc, f, h->xn, M, d, k.ln_eps, s));
+        GET(h, "ptf.ca.wi", 1u, &w, (size_t)k.d_ff * d);
+        { GemmArgs g{h->xn, w, h->ff, nullptr, M, k.d_ff, d, d, d, k.d_ff, 0, 0, 0}; LAUNCH(launch_gemm(EPI_BF16_RELU, g, s)); }
+        GET(h, "ptf.ca.wo2", 1u, &w, (size_t)d * k.d_ff);
+        { GemmArgs g{h->ff, w, h->h_enc, nullptr, M, d, k.d_ff, k.d_ff, k.d_ff, d, 0, 0, 0}; LAUNCH(launch_gemm(EPI_RESID, g, s)); }
     }
     const float* bias_off;
     GET(h, "enc.bias_off", 0u, const_cast<float**>(&bias_off), (size_t)k.n_heads * (2 * h->T - 1));

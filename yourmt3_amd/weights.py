@@ -111,20 +111,21 @@ def make_weights(cfg: YMT3Config, seed: int = 1234) -> Dict[str, torch.Tensor]:
 
 
 def _perceiver_weights(cfg, W, g, mat, gain):
-    """Perceiver-TF encoder parameters (build-defined spec, see DESIGN.md section 'Perceiver-TF')."""
+    """Latent-array cross-attention front of the encoder (a9; build-defined spec).
+
+    `ptf.latents` (n_latents x d) is the learned query array; one cross-attention block (pre-norm on
+    queries and on the frame features, query residual, ReLU FFN) reads the projected frames, then the
+    `enc.*` T5 blocks run as latent self-attention."""
     d, dff, inner = cfg.d_model, cfg.d_ff, cfg.inner
     W["ptf.latents"] = mat(cfg.n_latents, d, 1.0)
-    for l in range(cfg.n_enc_layers):
-        p = f"ptf.{l}."
-        for name in ("sca", "lat", "tmp"):     # spectral cross-attn, latent self-attn, temporal self-attn
-            W[p + name + ".ln"] = gain(d)
-            W[p + name + ".wq"] = mat(inner, d, (d * cfg.d_kv) ** -0.5 * 4.0)
-            W[p + name + ".wkv"] = torch.cat([mat(inner, d, d ** -0.5), mat(inner, d, d ** -0.5)], 0)
-            W[p + name + ".wo"] = mat(d, inner, inner ** -0.5)
-        W[p + "sca.ln_kv"] = gain(d)
-        W[p + "ln_ff"] = gain(d)
-        W[p + "wi"] = mat(dff, d, d ** -0.5)
-        W[p + "wo2"] = mat(d, dff, dff ** -0.5)
+    W["ptf.ca.ln_q"] = gain(d)
+    W["ptf.ca.ln_kv"] = gain(d)
+    W["ptf.ca.wq"] = mat(inner, d, (d * cfg.d_kv) ** -0.5 * 4.0)
+    W["ptf.ca.wkv"] = torch.cat([mat(inner, d, d ** -0.5), mat(inner, d, d ** -0.5)], 0)
+    W["ptf.ca.wo"] = mat(d, inner, inner ** -0.5)
+    W["ptf.ca.ln_ff"] = gain(d)
+    W["ptf.ca.wi"] = mat(dff, d, d ** -0.5)
+    W["ptf.ca.wo2"] = mat(d, dff, dff ** -0.5)
 
 
 _BF16_SUFFIX = ("w", "wqkv", "wo", "wi", "wo2", "wq_c", "wkv_c", "wo_c", "embed", "chan_embed",
