@@ -21,6 +21,7 @@
 //                       stream, and the step counter advance by the last workgroup to finish.
 //
 // Oracle: oracle/ymt3_oracle.py::decoder_step / greedy_decode.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -32,18 +33,18 @@ constexpr int DKV = 64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
-// 512 threads = 8 waves; one workgroup = a (16*MT rows) x 16 columns output tile over the full K, each
-// wave owning K/8 of the reduction.  MT = 1 (16 rows) for R <= 128 keeps every workgroup's operand
-// traffic small (the per-CU load path is what bounds these kernels, not HBM); workgroups that share a
-// weight tile are placed on one XCD (same blockIdx % 8) so its re-reads hit that XCD's L2.
+// 512 threads = 8 waves; one workgroup = a 16 rows x 16 columns output tile over the full K, each wave
+// owning K/8 of the reduction.  Small tiles keep every workgroup's operand traffic small (the per-CU load
+// path is what bounds these kernels, not HBM); workgroups that share a weight tile are placed on one XCD
+// (same blockIdx % 8) so its re-reads hit that XCD's L2.
 //
-// Operand path (MT = 1): every wave pulls ITS K-slice of the 16 activation rows and 16 weight rows
+// Operand path: every wave pulls ITS K-slice of the 16 activation rows and 16 weight rows
 // with fully coalesced 16-byte loads (8..32 consecutive lanes per row = whole 128-byte lines), all
 // issued up front (one memory round trip), parks them in a wave-private LDS strip, and reads them
 // back in MFMA fragment order with ds_read_b128.  Fragment-shaped global loads (16 rows x 64 B per
 // instruction) measured 3-4x slower for the same bytes (profiles/r01_notes.md).  No workgroup barrier
 // is needed for the strip: only the owning wave touches it and LDS executes a wave's ops in order.
-// MT = 4 (multi-channel row counts) keeps direct fragment loads: its 64-row strips would not fit LDS.
+// (A 64-row-tile variant with direct fragment loads was measured 13-15 % slower at 256 and 832 rows and removed.)
 //
 // The RMS norm needs sum(x^2) over the FULL row, which no single wave sees: it is carried between
 // kernels as per-row partial sums `ssq[tile][row]` written by whoever last wrote the residual stream
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (MT == 1) {
+    {
         char* sA = strips + wave * 2 * STRIP;
         char* sW = sA + STRIP;
         // weight slice: LPRW lanes cover one row's KW bf16
@@ -159,76 +160,6 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + off);
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + off);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[0], 0, 0, 0);
-        }
-    } else {
-        const int kb = wave * KW + g * 8;
-        const bf16_t* wrow = a.W + (size_t)(n0 + li) * K + kb;
-        bf16x8 wf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + ks * 32));
-        int mrow[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int mm = m0 + mt * 16 + li;
-            mrow[mt] = mm < m_end ? mm : m_end - 1;
-        }
-        if constexpr (NORM) {
-            float4 xv[MT][KS][2];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const float4* px = reinterpret_cast<const float4*>(a.x_f32 + (size_t)mrow[mt] * K + kb + ks * 32);
-                    xv[mt][ks][0] = px[0];
-                    xv[mt][ks][1] = px[1];
-                }
-            float4 gv[KS][2];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float4* pg = reinterpret_cast<const float4*>(a.gain + kb + ks * 32);
-                gv[ks][0] = pg[0];
-                gv[ks][1] = pg[1];
-            }
-            float ss = 0.f;
-            if (epi) {
-                const int mm = m < m_end ? m : m_end - 1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ss += a.ssq[(size_t)((tid & 7) * 4 + j) * a.ssq_stride + mm];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ss += __shfl_xor(ss, 1, 64);
-            ss += __shfl_xor(ss, 2, 64);
-            ss += __shfl_xor(ss, 4, 64);
-            if (epi && (tid & 7) == 0) sscale[mr] = rsqrtf(ss / (float)K + a.eps);
-            __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float sc = sscale[mt * 16 + li];
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const float4 x0 = xv[mt][ks][0], x1 = xv[mt][ks][1], g0 = gv[ks][0], g1 = gv[ks][1];
-                    bf16x8 af;
-                    af[0] = (__bf16)(x0.x * sc * g0.x); af[1] = (__bf16)(x0.y * sc * g0.y);
-                    af[2] = (__bf16)(x0.z * sc * g0.z); af[3] = (__bf16)(x0.w * sc * g0.w);
-                    af[4] = (__bf16)(x1.x * sc * g1.x); af[5] = (__bf16)(x1.y * sc * g1.y);
-                    af[6] = (__bf16)(x1.z * sc * g1.z); af[7] = (__bf16)(x1.w * sc * g1.w);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af, acc[mt], 0, 0, 0);
-                }
-            }
-        } else {
-            bf16x8 af[MT][KS];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    af[mt][ks] = __builtin_bit_cast(
-                        bf16x8, *reinterpret_cast<const uint4*>(a.a_bf16 + (size_t)mrow[mt] * K + kb + ks * 32));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[mt][ks], acc[mt], 0, 0, 0);
         }
     }
 
@@ -509,28 +440,18 @@ __global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_ch
     }
 }
 
-template <int MODE, int K, int MT>
+template <int MODE, int K>
 constexpr size_t dg_lds_bytes() {
-    return (size_t)(8 * 16 * MT * 16 + 16 * MT) * 4 + (MT == 1 ? (size_t)8 * 2 * 16 * (K / 8 * 2 + 16) : 0);
+    return (size_t)(8 * 16 * 16 + 16) * 4 + (size_t)8 * 2 * 16 * (K / 8 * 2 + 16);
 }
 
 template <int MODE, int K>
 int launch_dg(const DecGemmArgs& a, hipStream_t stream) {
-    if (a.W == nullptr) {   // attribute-only call from init_decode_kernels(): > 64 KB of dynamic LDS needs opting in
-        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, 1>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K, 1>());
-        const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, 4>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K, 4>());
-        return (e1 == hipSuccess && e4 == hipSuccess) ? 0 : -2;
-    }
+    if (a.W == nullptr)     // attribute-only call from init_decode_kernels(): > 64 KB of dynamic LDS needs opting in
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K>()) == hipSuccess ? 0 : -2;
     if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;   // the norm consumers sum exactly SSQ_TILES partials
-    if (a.R <= 128) {
-        const int n_mt = (a.R + 15) / 16;
-        dec_gemm_kernel<MODE, K, 1><<<(a.N / 16) * n_mt, 512, dg_lds_bytes<MODE, K, 1>(), stream>>>(a);
-    } else {
-        const int n_mt = (a.R + 63) / 64;
-        dec_gemm_kernel<MODE, K, 4><<<(a.N / 16) * n_mt, 512, dg_lds_bytes<MODE, K, 4>(), stream>>>(a);
-    }
+    dec_gemm_kernel<MODE, K, 1><<<(a.N / 16) * ((a.R + 15) / 16), 512, dg_lds_bytes<MODE, K>(), stream>>>(a);
     return 0;
 }
 
