@@ -160,24 +160,34 @@ def main():
         rows = B * cfg.n_channels
         bytes_total = sum(self_attn_algorithmic_bytes(cfg, rows, t) for t in sampled_t) * cfg.n_dec_layers
         assert sa["launches"] == len(sampled_t) * cfg.n_dec_layers, (sa, len(sampled_t))
-        avg_ms = sa["ms_total"] / sa["launches"]
-        achieved = bytes_total / (sa["ms_total"] * 1e-3) / 1e9
+        # An event pair costs stream time of its own, so per-launch brackets over-read.  Calibrate against the true step
+        # time (one bracket around the stride-1 un-bracketed steps after every sampled step): the per-bracket overhead
+        # is (sum of all brackets of a sampled step - true step time) / launches per step.
+        span = prof["unsampled_span"]
+        kern = {k: v for k, v in prof.items() if k != "unsampled_span"}
+        n_sampled = len(sampled_t)
+        step_true_ms = span["ms_total"] / max(1, span["launches"] * (args.profile_stride - 1))
+        launches_per_step = sum(v["launches"] for v in kern.values()) / n_sampled
+        pair_ms = max(0.0, (sum(v["ms_total"] for v in kern.values()) / n_sampled - step_true_ms) / launches_per_step)
+        avg_ms = sa["ms_total"] / sa["launches"] - pair_ms
+        achieved = (bytes_total / sa["launches"]) / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {
             "kernel": "dec_attn_kernel<true> (decoder self-attention over the KV cache)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic(cfg, B, L),
-            "avg_launch_us": 1e3 * avg_ms, "launches_timed": sa["launches"],
+            "avg_launch_us": 1e3 * avg_ms, "launches_timed": sa["launches"], "event_pair_overhead_us": 1e3 * pair_ms,
+            "eager_step_us": 1e3 * step_true_ms,
             "algorithmic_bytes_per_launch": bytes_total / sa["launches"],
             "note": "bytes = rows*heads*(t+1)*64*2B*2 (K and V) averaged over sampled positions t = stride/2, 3*stride/2, ...; "
-                    "duration = HIP events around each sampled launch on the launch stream; traffic = FETCH_SIZE*2 + "
+                    "duration = HIP events around each sampled launch on the launch stream minus the per-bracket overhead calibrated against un-bracketed steps; traffic = FETCH_SIZE*2 + "
                     "WRITE_SIZE per launch from profiles/r01_pmc_decode_attn.json (separate rocprofv3 --pmc passes)",
         }
-        step_ms = {k: (v["ms_total"] / max(1, v["launches"])) * (cfg.n_dec_layers if k not in ("lm_head_gemm", "argmax_embed") else 1)
-                   for k, v in prof.items()}
+        step_ms = {k: max(0.0, v["ms_total"] / max(1, v["launches"]) - pair_ms) * (cfg.n_dec_layers if k not in ("lm_head_gemm", "argmax_embed") else 1)
+                   for k, v in kern.items()}
         result["decode_step_breakdown_us"] = {k: round(1e3 * v, 2) for k, v in step_ms.items()}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(baseline_config(0).with_(eos_id=-1), sample_segments=2, sample_steps=512)
+        result["cpu_baseline"] = cpu_baseline(baseline_config(0).with_(eos_id=-1), sample_segments=4, sample_steps=1024)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -84,7 +84,9 @@ int ymt3_transcribe_segments(ymt3_handle h, const float* audio_dev, int B, int n
 /* Measurement hook (bench.py `roofline`): decode eagerly (no graph) and bracket every kernel launch of
  * every `stride`-th step (positions stride/2, 3*stride/2, ...) with HIP events on `stream`; synchronises the stream before returning.
  * Classes: 0 qkv+cache GEMM, 1 self-attention, 2 self O-proj, 3 cross Q GEMM, 4 cross-attention,
- * 5 cross O-proj, 6 FFN wi, 7 FFN wo, 8 lm_head, 9 argmax+embed.  Outputs are HOST arrays. */
+ * 5 cross O-proj, 6 FFN wi, 7 FFN wo, 8 lm_head, 9 argmax+embed, 10 spans: ONE bracket around the stride-1
+ * un-bracketed steps after each sampled step (true step time, used to calibrate out the stream time an
+ * event pair itself costs).  Outputs are HOST arrays. */
 #define YMT3_PROFILE_CLASSES 16
 int ymt3_profile_decode(ymt3_handle h, const void* enc_dev, int B, int n_steps, int stride, int32_t* tokens_dev,
                         float* ms_by_class, int32_t* launches_by_class, void* stream);

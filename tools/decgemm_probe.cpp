@@ -67,5 +67,24 @@ int main() {
     }
     t.k = ck; t.v = ck + (size_t)R * H * T * 64; t.slab_keys = T; t.n_keys_const = T; t.bias = nullptr;
     timeit("cross-attn T=256 (same slabs)", [&](int) { launch_dec_attention(false, t, st); }, st, 200);
+    // interaction between consecutive kernels: pairs and the whole 8-kernel layer sequence, rotating over 6 layers
+    hs.step = 511; CK(hipMemcpy(sh, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    DecAttnArgs ts = t; ts.slab_keys = L; ts.rows_per_kv = 1; ts.n_keys_const = 0; ts.bias = h;
+    DecAttnArgs tc = t;
+    auto Wl = [&](int i, size_t off) { return w + (size_t)(i % NL) * (wbytes / 2 / NL) + off; };
+    auto self_attn = [&](int i) { ts.k = kc + (size_t)(i % NL) * (cache / 2); ts.v = vc + (size_t)(i % NL) * (cache / 2); launch_dec_attention(true, ts, st); };
+    auto resid512 = [&](int i, size_t off) { a.W = Wl(i, off); a.N = d; a.K = d; a.out_bf16 = q; launch_dec_gemm(DG_RESID, a, st); };
+    auto norm512 = [&](int i, size_t off) { a.W = Wl(i, off); a.N = d; a.K = d; a.out_bf16 = q; launch_dec_gemm(DG_NORM_BF16, a, st); };
+    auto qkv = [&](int i) { a.W = Wl(i, 0); a.N = 3 * d; a.K = d; a.out_bf16 = q; launch_dec_gemm(DG_NORM_QKV_CACHE, a, st); };
+    auto wi = [&](int i) { a.W = Wl(i, (size_t)d * d * 5); a.N = dff; a.K = d; a.out_bf16 = abf; launch_dec_gemm(DG_NORM_BF16_RELU, a, st); a.out_bf16 = q; };
+    auto wo2 = [&](int i) { a.W = Wl(i, (size_t)d * d * 5); a.N = d; a.K = dff; launch_dec_gemm(DG_RESID, a, st); };
+    timeit("pair: self-attn(t=511) + RESID512", [&](int i) { self_attn(i); resid512(i, (size_t)d * d * 3); }, st, 120);
+    timeit("pair: RESID512 + NORM512", [&](int i) { resid512(i, (size_t)d * d * 3); norm512(i, (size_t)d * d * 4); }, st, 240);
+    timeit("pair: cross-attn + RESID512", [&](int i) { launch_dec_attention(false, tc, st); resid512(i, (size_t)d * d * 3); }, st, 240);
+    timeit("layer: qkv,self,o,crossq,cross,oc,wi,wo2 (t=511)", [&](int i) {
+        qkv(i); self_attn(i); resid512(i, (size_t)d * d * 3); norm512(i, (size_t)d * d * 4); launch_dec_attention(false, tc, st);
+        resid512(i, (size_t)d * d * 3); wi(i); wo2(i); }, st, 60);
+    timeit("layer without the two attention kernels", [&](int i) {
+        qkv(i); resid512(i, (size_t)d * d * 3); norm512(i, (size_t)d * d * 4); resid512(i, (size_t)d * d * 3); wi(i); wo2(i); }, st, 60);
     return 0;
 }

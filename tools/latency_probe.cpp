@@ -29,14 +29,14 @@ __global__ void k_load_sync_store(Args p) {   // load -> LDS reduce -> store
 // PREVIOUS kernel wrote (ping-pong), reduces, and writes 2 KB: the shape of a skinny decode GEMM
 template <int NLOAD>
 __global__ __launch_bounds__(512) void k_pull(const float4* src, float4* dst, int wg_stride4) {
-    const float4* p = src + (size_t)(blockIdx.x % 64) * wg_stride4 + threadIdx.x;
+    const float4* p = src + (size_t)blockIdx.x * wg_stride4 + threadIdx.x;
     float4 v[NLOAD];
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) v[i] = p[i * 512];
     float4 s = make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
-    dst[(size_t)(blockIdx.x % 64) * wg_stride4 + threadIdx.x] = s;
+    dst[(size_t)(blockIdx.x % 64) * 512 + threadIdx.x] = s;
 }
 template <int NLOAD>
 static int run_pull(int grid, hipStream_t st, float4* a, float4* b, int n) {
@@ -89,14 +89,36 @@ int main() {
         run("load->lds->store", k_load_sync_store, p, grid, 512, st, 1000);
     }
     float4 *pa, *pb;
-    CK(hipMalloc((void**)&pa, 64 * 32 * 512 * 16)); CK(hipMalloc((void**)&pb, 64 * 32 * 512 * 16));
-    CK(hipMemset(pa, 0, 64 * 32 * 512 * 16)); CK(hipMemset(pb, 0, 64 * 32 * 512 * 16));
+    CK(hipMalloc((void**)&pa, (size_t)384 * 32 * 512 * 16)); CK(hipMalloc((void**)&pb, (size_t)384 * 32 * 512 * 16));
+    CK(hipMemset(pa, 0, (size_t)384 * 32 * 512 * 16)); CK(hipMemset(pb, 0, (size_t)384 * 32 * 512 * 16));
     for (int grid : {32, 128, 384}) {
         run_pull<1>(grid, st, pa, pb, 1000);
         run_pull<4>(grid, st, pa, pb, 1000);
         run_pull<8>(grid, st, pa, pb, 1000);
         run_pull<16>(grid, st, pa, pb, 1000);
         run_pull<32>(grid, st, pa, pb, 1000);
+    }
+    // where do re-read weights come from?  read-only pulls of 32 KB per WG, 128 WGs (4 MB per launch), cycling over
+    // `nbuf` distinct 4 MB buffers: 1 -> whatever survives a kernel boundary closest to the CU; 8 (32 MB) -> beyond one
+    // XCD's 4 MB L2; 48 (192 MB) -> Infinity Cache; 160 (640 MB) -> HBM
+    {
+        const size_t per = 128 * 4 * 512 * 16;      // bytes per buffer
+        float4* big; CK(hipMalloc((void**)&big, per * 160)); CK(hipMemset(big, 0, per * 160));
+        for (int nbuf : {1, 8, 48, 160}) {
+            hipGraph_t g; hipGraphExec_t e;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < 960; ++i)
+                k_pull<4><<<128, 512, 0, st>>>(big + (size_t)(i % nbuf) * (per / 16), pb, 4 * 512);
+            CK(hipStreamEndCapture(st, &g));
+            CK(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(e, st)); CK(hipStreamSynchronize(st));
+            auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(e, st));
+            CK(hipStreamSynchronize(st));
+            printf("read-only 32 KB/WG x 128 WGs cycling %3d x 4 MB buffers: %.2f us per kernel\n", nbuf,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (3.0 * 960));
+            hipGraphExecDestroy(e); hipGraphDestroy(g);
+        }
     }
     return 0;
 }

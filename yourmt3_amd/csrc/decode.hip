@@ -223,10 +223,17 @@ __device__ __forceinline__ float sum8(float v) {
     return v;
 }
 
-template <bool SELF>
-__global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
+// FUSEQ (cross-attention only): the query projection of the block,  q = R( R(rmsnorm(h_r) * gain) . Wq[head]^T ),  is
+// computed inside this kernel instead of by a separate skinny GEMM launch.  Its operands (64 weight rows of this
+// head, the residual row, the sum(h^2) partials) are independent of the K/V stream, so they are issued first and
+// the whole projection runs while the K/V loads are in flight: one kernel boundary (~5 us in situ) less per layer.
+template <bool SELF, bool FUSEQ>
+__global__ __launch_bounds__(512, 4) void dec_attn_kernel(DecAttnArgs a) {   // (512, 4): 4 waves / SIMD = two workgroups per CU -> <= 128 VGPRs
     constexpr int NW = 8;                       // waves per (row, head): 16 waves / CU keep > 12 MB in flight chip-wide
     __shared__ float sm[NW], sl[NW], sacc[NW][DKV];
+    __shared__ __attribute__((aligned(16))) float xs[FUSEQ ? 512 : 4];
+    __shared__ __attribute__((aligned(16))) bf16_t qs[DKV];
+    __shared__ float s_scale;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane & 7, kg = lane >> 3;
@@ -239,7 +246,20 @@ __global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
     const float* bias = SELF ? a.bias + (size_t)h * a.bias_stride : nullptr;
 
     // q stays packed (4 x bf16x2); halves are widened to fp32 at use
-    const u32x4 qp = *reinterpret_cast<const u32x4*>(a.q + ((size_t)r * a.H + h) * DKV + sub * 8);
+    u32x4 qp;
+    u32x4 wq_v[FUSEQ ? 8 : 1];
+    float x_v = 0.f, g_v = 0.f, ss = 0.f;
+    if constexpr (FUSEQ) {
+        // operands of the fused projection: wave w owns outputs 8w..8w+7, lane l the k-chunk 8l..8l+7
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            wq_v[jj] = *reinterpret_cast<const u32x4*>(a.wq + ((size_t)h * DKV + wave * 8 + jj) * 512 + lane * 8);
+        x_v = a.x_f32[(size_t)r * 512 + tid];
+        g_v = a.gain[tid];
+        if (tid < SSQ_TILES) ss = a.ssq[(size_t)tid * a.ssq_stride + r];
+    } else {
+        qp = *reinterpret_cast<const u32x4*>(a.q + ((size_t)r * a.H + h) * DKV + sub * 8);
+    }
 
     float m = -1.0e30f, l = 0.f, acc[8];
 #pragma unroll
@@ -250,12 +270,10 @@ __global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
     // re-read every step, out of the 256 MB Infinity Cache.  Up to 16 x 16-byte loads in flight per lane;
     // blocks of 64 keys that lie wholly beyond n_keys are skipped wave-uniformly (loads AND math), so
     // early positions do not pay for the unrolled tail.
-    constexpr int U = SELF ? 8 : 4;            // cross: 8 waves x 8 keys x 4 = 256 frames in one shot
-    auto block = [&](int kw, int nblk, auto full_tag) {
+    constexpr int U = SELF ? 6 : 4;            // self: 12 loads in flight per lane (8 would spill at 128 VGPRs); cross: 8 x 8 x 4 = 256 frames in one shot
+    auto load_block = [&](u32x4 (&ku)[U], u32x4 (&vu)[U], bool (&ok)[U], int kw, int nblk, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;         // FULL: all U blocks valid, branch-free
         const int k0 = kw + kg;
-        u32x4 ku[U], vu[U];
-        bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int key = k0 + 8 * NW * u;
@@ -271,6 +289,10 @@ __global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
                 }
             }
         }
+    };
+    auto compute_block = [&](u32x4 (&ku)[U], u32x4 (&vu)[U], bool (&ok)[U], int kw, int nblk, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int k0 = kw + kg;
         float sc[U];
         float mn = m;
 #pragma unroll
@@ -308,11 +330,58 @@ __global__ __launch_bounds__(512) void dec_attn_kernel(DecAttnArgs a) {
         }
         m = mn;
     };
-    for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {     // wave-uniform trip count
-        // wave-uniform: blocks of 64 keys holding at least one valid key for this wave
-        const int nblk = (n_keys - kw + 8 * NW - 1) / (8 * NW);
-        if (n_keys - kw >= 8 * NW * U) block(kw, U, std::true_type{});
-        else block(kw, nblk, std::false_type{});
+    u32x4 fku[FUSEQ ? U : 1], fvu[FUSEQ ? U : 1];             // FUSEQ: the first K/V block lives across the projection
+    bool fok[FUSEQ ? U : 1];
+    if constexpr (!FUSEQ) {
+        auto block = [&](int kw, int nblk, auto full_tag) {      // staging registers scoped to one block
+            u32x4 ku[U], vu[U];
+            bool ok[U];
+            load_block(ku, vu, ok, kw, nblk, full_tag);
+            compute_block(ku, vu, ok, kw, nblk, full_tag);
+        };
+        for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {     // wave-uniform trip count
+            // wave-uniform: blocks of 64 keys holding at least one valid key for this wave
+            const int nblk = (n_keys - kw + 8 * NW - 1) / (8 * NW);
+            if (n_keys - kw >= 8 * NW * U) block(kw, U, std::true_type{});
+            else block(kw, nblk, std::false_type{});
+        }
+    } else if (wave * 8 < n_keys) {
+        // first (for T <= 256: only) K/V block goes in flight now; its math waits for the projection below
+        const int kw = wave * 8, nblk = (n_keys - kw + 8 * NW - 1) / (8 * NW);
+        load_block(fku, fvu, fok, kw, nblk < U ? nblk : U, std::false_type{});
+    }
+    if constexpr (FUSEQ) {
+        // norm scale (fixed-order tree over the 32 partials), normed row -> LDS as bf16-rounded floats
+        ss = wave_sum(ss);
+        if (tid == 0) s_scale = rsqrtf(ss / 512.f + a.eps);
+        __syncthreads();
+        xs[tid] = bf2f(f2bf(x_v * s_scale * g_v));
+        __syncthreads();
+        float xn[8];
+        *reinterpret_cast<float4*>(xn) = *reinterpret_cast<const float4*>(xs + lane * 8);
+        *reinterpret_cast<float4*>(xn + 4) = *reinterpret_cast<const float4*>(xs + lane * 8 + 4);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d = fmaf(xn[2 * j], __uint_as_float(wq_v[jj][j] << 16), d);
+                d = fmaf(xn[2 * j + 1], __uint_as_float(wq_v[jj][j] & 0xffff0000u), d);
+            }
+            d = sum8(d);
+            d += DPP_F(d, 0x128);                                 // row_ror:8 -> lane ^ 8 within the row of 16
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            if (lane == jj) qs[wave * 8 + jj] = f2bf(d);
+        }
+        __syncthreads();
+        qp = *reinterpret_cast<const u32x4*>(qs + sub * 8);
+        // the block loaded above, then (T > 256 only) the remaining ones
+        for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {
+            const int nb = (n_keys - kw + 8 * NW - 1) / (8 * NW), nblk = nb < U ? nb : U;
+            if (kw != wave * 8) load_block(fku, fvu, fok, kw, nblk, std::false_type{});
+            compute_block(fku, fvu, fok, kw, nblk, std::false_type{});
+        }
     }
     // merge the 8 key groups of the wave (lanes with equal `sub`)
 #pragma unroll
@@ -491,8 +560,9 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
 
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
-    if (self_attn) dec_attn_kernel<true><<<a.R * a.H, 512, 0, stream>>>(a);
-    else dec_attn_kernel<false><<<a.R * a.H, 512, 0, stream>>>(a);
+    if (self_attn) dec_attn_kernel<true, false><<<a.R * a.H, 512, 0, stream>>>(a);
+    else if (a.wq) dec_attn_kernel<false, true><<<a.R * a.H, 512, 0, stream>>>(a);
+    else dec_attn_kernel<false, false><<<a.R * a.H, 512, 0, stream>>>(a);
     return 0;
 }
 

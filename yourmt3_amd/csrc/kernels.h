@@ -94,6 +94,12 @@ struct DecAttnArgs {
     int slab_keys;              // keys allocated per (row, head) slab (L for self, T for cross)
     int rows_per_kv;            // 1 for self; n_channels for cross (row r reads segment r / n_channels)
     int row0, R, H, bias_stride;
+    // fused query projection (cross-attention; wq == nullptr -> q is read from `q`): q = R(R(norm(x_r)*gain) . wq[head]^T)
+    const bf16_t* wq;           // [H*64][512]
+    const float* x_f32;         // [R][512] residual stream
+    const float* gain;          // [512]
+    const float* ssq; int ssq_stride;
+    float eps;
 };
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream);
 

@@ -84,14 +84,17 @@ struct ymt3_ctx {
     hipEvent_t fork_ev = nullptr, join_ev[8] = {};
     std::map<long, StepGraph> step_graphs;  // keyed by (B, n_chains_used, chain)
     bool use_graph = true;
+    bool fuse_q = true;                     // cross-attention computes its own query projection
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
+    size_t prof_span_idx = 0;
+    bool prof_span_open = false;
     int prof_step0 = 0;                     // ymt3_set_profile_start: decode positions begin here (measurement only)
     std::vector<hipEvent_t> prof_ev;        // pairs
     std::vector<int> prof_cls;
 };
 
-enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_COUNT };
+enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_COUNT };
 
 struct ProfScope {
     ymt3_ctx* c; hipStream_t s; bool on;
@@ -281,6 +284,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     const char* ng = getenv("YMT3_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
+    const char* nf = getenv("YMT3_NO_FUSEQ");
+    c->fuse_q = !(nf && nf[0] == '1');
     const char* nc = getenv("YMT3_CHAINS");
     if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
     for (int i = 0; i < c->n_chains; ++i) {
@@ -453,11 +458,16 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
         a.a_bf16 = h->dattn; a.W = W.wo; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
         PLAUNCH(PC_SELF_O, launch_dec_gemm(DG_RESID, a, s));
-        // cross-attention block
-        a.gain = W.ln2; a.W = W.wq_c; a.N = inner; a.K = d; a.out_bf16 = h->dq;
-        PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
+        // cross-attention block: the query projection is fused into the attention kernel (YMT3_NO_FUSEQ=1 keeps
+        // the separate skinny GEMM, for A/B measurements)
         t.k = h->ckv + (size_t)(2 * l) * slab; t.v = h->ckv + (size_t)(2 * l + 1) * slab; t.bias = nullptr;
         t.n_keys_const = h->T; t.slab_keys = h->T; t.rows_per_kv = k.n_channels;
+        if (h->fuse_q) {
+            t.wq = W.wq_c; t.x_f32 = h->h_dec; t.gain = W.ln2; t.ssq = h->ssq; t.ssq_stride = h->maxR; t.eps = k.ln_eps;
+        } else {
+            a.gain = W.ln2; a.W = W.wq_c; a.N = inner; a.K = d; a.out_bf16 = h->dq;
+            PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
+        }
         PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
         a.a_bf16 = h->dattn; a.W = W.wo_c; a.N = d; a.K = inner;
         PLAUNCH(PC_CROSS_O, launch_dec_gemm(DG_RESID, a, s));
@@ -512,11 +522,31 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
     for (int c = 0; c < n_chains; ++c) row0[c + 1] = row0[c] + R / n_chains + (c < R % n_chains ? 1 : 0);
 
     if (!h->use_graph || prof_stride > 0) {
+        // sampled steps (mid-stride: unbiased mean position) bracket every launch; the stride-1 unsampled steps that
+        // follow each of them are bracketed as ONE span, which gives the true step time the per-launch brackets are
+        // calibrated against (an event pair adds stream time of its own)
         for (int t = 0; t < n_steps; ++t) {
-            h->prof_on = prof_stride > 0 && (t % prof_stride) == prof_stride / 2;   // mid-stride: unbiased mean position
+            const bool sampled = prof_stride > 0 && (t % prof_stride) == prof_stride / 2;
+            const bool span_begin = prof_stride > 1 && (t % prof_stride) == prof_stride / 2 + 1 && t + prof_stride - 1 <= n_steps;
+            const bool span_end = prof_stride > 1 && t >= prof_stride && (t % prof_stride) == prof_stride / 2 && !h->prof_ev.empty() && h->prof_span_open;
+            if (span_end) { (void)hipEventRecord(h->prof_ev[h->prof_span_idx], s); h->prof_span_open = false; }
+            if (span_begin) {
+                hipEvent_t ea, eb;
+                if (hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess) {
+                    h->prof_ev.push_back(ea); h->prof_ev.push_back(eb); h->prof_cls.push_back(PC_SPAN);
+                    h->prof_span_idx = h->prof_ev.size() - 1; h->prof_span_open = true;
+                    (void)hipEventRecord(ea, s);
+                }
+            }
+            h->prof_on = sampled;
             int rc = launch_step(h, B, 0, R, h->shared, s);
             h->prof_on = false;
             if (rc) return rc;
+        }
+        if (h->prof_span_open) {            // a span the loop never closed: drop it (its end event was never recorded)
+            (void)hipEventRecord(h->prof_ev[h->prof_span_idx], s);
+            h->prof_cls[h->prof_span_idx / 2] = -1;
+            h->prof_span_open = false;
         }
     } else {
         hipGraphExec_t exec[8];
@@ -595,7 +625,8 @@ extern "C" int ymt3_profile_decode(ymt3_handle h, const void* enc_dev, int B, in
     for (int i = 0; i < YMT3_PROFILE_CLASSES; ++i) { ms_by_class[i] = 0.f; launches_by_class[i] = 0; }
     for (size_t i = 0; i < h->prof_cls.size(); ++i) {
         float ms = 0.f;
-        if (rc == 0 && e == hipSuccess && hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) == hipSuccess) {
+        if (rc == 0 && e == hipSuccess && h->prof_cls[i] >= 0 &&
+            hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) == hipSuccess) {
             ms_by_class[h->prof_cls[i]] += ms;
             launches_by_class[h->prof_cls[i]] += 1;
         }
