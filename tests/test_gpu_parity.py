@@ -296,6 +296,80 @@ def test_perceiver_latent_encoder_matches_oracle():
         _model(cfg.with_(n_latents=32))                             # latent length is tied to the frame count
 
 
+def test_two_concurrent_chains_and_unfused_query_path_give_identical_tokens(small):
+    """YMT3_CHAINS / YMT3_NO_FUSEQ are read at create: rows are independent, so any split must be bit-identical;
+    the fused and the separate query projection follow the same rounding points (ids equal where margins allow)."""
+    cfg = SMALL
+    a = O.synthetic_audio(4, cfg, seed=5).cuda()
+    e = small.encode(small.logmel(a))
+    ref = small.decode(e, 40).cpu()
+    os.environ["YMT3_CHAINS"] = "2"
+    try:
+        m2 = _model(cfg)
+    finally:
+        del os.environ["YMT3_CHAINS"]
+    assert torch.equal(m2.decode(e, 40).cpu(), ref)
+    m2.close()
+    os.environ["YMT3_NO_FUSEQ"] = "1"
+    try:
+        m3 = _model(cfg)
+    finally:
+        del os.environ["YMT3_NO_FUSEQ"]
+    t3, l3 = m3.decode(e, 40, forced=ref.cuda(), return_logits=True)
+    t1, l1 = small.decode(e, 40, forced=ref.cuda(), return_logits=True)
+    m3.close()
+    assert (l3 - l1).abs().max().item() < 0.02
+    safe = _margin(l1.cpu()) >= TAU
+    assert torch.equal(t3.cpu()[safe], t1.cpu()[safe])
+
+
+def test_profile_hooks(small):
+    e = small.encode(small.logmel(O.synthetic_audio(2, SMALL).cuda()))
+    prof = small.profile_decode(e, 32, stride=8)
+    assert prof["self_attn"]["launches"] == 4 * SMALL.n_dec_layers and prof["self_attn"]["ms_total"] > 0
+    assert prof["lm_head_gemm"]["launches"] == 4 and prof["unsampled_span"]["launches"] == 3
+    ref = small.decode(e, 16).cpu()
+    from yourmt3_amd import _lib
+    _lib.check(small._lib.ymt3_set_profile_start(small._handle, 8))
+    try:
+        with pytest.raises(_lib.YMT3Error):
+            small.decode(e, SMALL.max_decode_len)              # 8 + 64 > max_decode_len
+        assert small.decode(e, 16).shape == (2, 1, 16)         # runs from position 8; ids are not meaningful
+    finally:
+        _lib.check(small._lib.ymt3_set_profile_start(small._handle, 0))
+    assert torch.equal(small.decode(e, 16).cpu(), ref)
+
+
+def test_bad_blob_and_config_are_rejected():
+    import ctypes
+    from yourmt3_amd import _lib
+    from yourmt3_amd.config import to_c
+    from yourmt3_amd.tables import derived_tables
+    from yourmt3_amd.weights import pack_blob
+    lib = _lib.load()
+    cfg = SMALL
+    W = make_weights(cfg)
+    full = {**W, **derived_tables(W, cfg)}
+    def create(blob, c=cfg):
+        h = ctypes.c_void_p()
+        cc = to_c(c, 2)
+        rc = lib.ymt3_create(ctypes.byref(cc), ctypes.create_string_buffer(blob, len(blob)), len(blob), 0, ctypes.byref(h))
+        if rc == 0:
+            lib.ymt3_destroy(h)
+        return rc, lib.ymt3_last_error().decode()
+    assert create(pack_blob(full))[0] == 0
+    rc, msg = create(b"NOTABLOB" + bytes(64))
+    assert rc == 2 and "magic" in msg
+    rc, msg = create(pack_blob({k: v for k, v in full.items() if k != "dec.3.wo"}))
+    assert rc == 2 and "dec.3.wo" in msg
+    rc, msg = create(pack_blob({k: v for k, v in full.items() if k != "fe.window"}))
+    assert rc == 2 and "fe.window" in msg
+    rc, msg = create(pack_blob(full), cfg.with_(d_kv=32, n_heads=16))
+    assert rc == 4
+    rc, msg = create(pack_blob(full), cfg.with_(segment_samples=8191 + 128))      # 65 frames: not a multiple of 64
+    assert rc == 4 and "n_frames" in msg
+
+
 def test_bad_arguments_raise(small):
     from yourmt3_amd._lib import YMT3Error
     e = torch.zeros(1, SMALL.n_frames, SMALL.d_model, dtype=torch.bfloat16).cuda()
