@@ -1,0 +1,94 @@
+"""Importer: HF-T5-named weights -> this build's tensors.  CPU: the imported weights reproduce
+HF's own outputs through the oracle.  GPU: the HIP path on imported weights against HF T5 itself (fp32), i.e. the
+third-party arithmetic directly, not only this build's oracle."""
+import pytest
+import torch
+
+from oracle import ymt3_oracle as O
+from yourmt3_amd.config import YMT3Config
+from yourmt3_amd.importer import from_t5_state_dict
+
+CFG = YMT3Config(segment_samples=8191, max_decode_len=32)
+
+
+def _hf(seed=3):
+    from transformers import T5Config, T5ForConditionalGeneration
+    torch.manual_seed(seed)
+    hc = T5Config(vocab_size=CFG.vocab, d_model=CFG.d_model, d_kv=CFG.d_kv, d_ff=CFG.d_ff, num_layers=CFG.n_enc_layers,
+                  num_decoder_layers=CFG.n_dec_layers, num_heads=CFG.n_heads, feed_forward_proj="relu", dropout_rate=0.0,
+                  layer_norm_epsilon=CFG.ln_eps, decoder_start_token_id=CFG.pad_id, pad_token_id=CFG.pad_id, eos_token_id=CFG.eos_id,
+                  tie_word_embeddings=False, attn_implementation="eager")
+    m = T5ForConditionalGeneration(hc).eval()
+    with torch.no_grad():                     # untie + give the head and embeddings some spread, then make everything bf16-exact
+        m.lm_head.weight = torch.nn.Parameter(torch.randn(CFG.vocab, CFG.d_model) * CFG.d_model ** -0.5)
+        m.shared.weight.copy_(torch.randn(CFG.vocab, CFG.d_model) * 4.0)
+        for p in m.parameters():
+            if p.dim() == 2 and p.shape != (CFG.rel_buckets, CFG.n_heads):
+                p.copy_(p.to(torch.bfloat16).float())
+    return m
+
+
+def _imported(m):
+    sd = dict(m.state_dict())
+    sd["lm_head.weight"] = m.lm_head.weight
+    g = torch.Generator().manual_seed(1)
+    return from_t5_state_dict(sd, CFG, in_proj_w=torch.randn(CFG.d_model, CFG.n_mels, generator=g) * 0.02,
+                              in_proj_b=torch.zeros(CFG.d_model))
+
+
+def test_imported_weights_reproduce_hf_through_the_oracle():
+    m = _hf()
+    W = _imported(m)
+    a = O.synthetic_audio(2, CFG)
+    h0 = O.input_projection(O.logmel(a, CFG), W, bf16=False)
+    enc = O.encoder_t5(h0, W, CFG, bf16=False)
+    with torch.no_grad():
+        ref = m.encoder(inputs_embeds=h0).last_hidden_state
+    assert (enc - ref).abs().max().item() < 2e-4
+    from transformers.modeling_outputs import BaseModelOutput
+    with torch.no_grad():
+        out = m.generate(encoder_outputs=BaseModelOutput(last_hidden_state=enc), max_new_tokens=12, min_new_tokens=12,
+                         do_sample=False, num_beams=1)
+    assert torch.equal(O.greedy_decode(enc, W, CFG, 12, bf16=False)[:, 0].long(), out[:, 1:])
+
+
+def test_importer_rejects_mismatched_shapes():
+    m = _hf()
+    sd = dict(m.state_dict())
+    sd["lm_head.weight"] = m.lm_head.weight
+    with pytest.raises(ValueError):
+        from_t5_state_dict(sd, CFG.with_(vocab=1024))
+    sd["encoder.final_layer_norm.weight"] = torch.full((CFG.d_model,), float("nan"))
+    with pytest.raises(ValueError):
+        from_t5_state_dict(sd, CFG)
+
+
+@pytest.mark.gpu
+def test_hip_path_on_imported_weights_matches_hf_t5_directly():
+    from yourmt3_amd.model import YourMT3
+    m = _hf()
+    W = _imported(m)
+    model = YourMT3(CFG, W, device=0, max_batch=2)
+    a = O.synthetic_audio(2, CFG)
+    mel = model.logmel(a.cuda())
+    enc = model.encode(mel)
+    h0 = O.input_projection(mel.cpu(), W, bf16=False)
+    with torch.no_grad():
+        ref_enc = m.encoder(inputs_embeds=h0).last_hidden_state
+    # bf16 operands vs HF fp32: a few percent of the unit-RMS output
+    assert (enc.float().cpu() - ref_enc).abs().max().item() < 0.12
+    assert (enc.float().cpu() - ref_enc).abs().mean().item() < 0.01
+    n = 10
+    from transformers.modeling_outputs import BaseModelOutput
+    with torch.no_grad():
+        out = m.generate(encoder_outputs=BaseModelOutput(last_hidden_state=enc.float().cpu()), max_new_tokens=n, min_new_tokens=n,
+                         do_sample=False, num_beams=1, output_logits=True, return_dict_in_generate=True)
+    hf_tokens = out.sequences[:, 1:]
+    hf_logits = torch.stack(out.logits, 1)
+    got_t, got_l = model.decode(enc, n, forced=hf_tokens[:, None, :].int().cuda(), return_logits=True)
+    d = (got_l.cpu()[:, 0] - hf_logits).abs()
+    assert d.max().item() < 0.25 and d.mean().item() < 0.03
+    top2 = hf_logits.topk(2, -1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 0.5
+    assert safe.any() and torch.equal(got_t.cpu()[:, 0][safe], hf_tokens[safe].int())
+    model.close()
