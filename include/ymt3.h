@@ -48,7 +48,7 @@ typedef struct ymt3_config {
     float   ln_eps;
     int32_t max_decode_len, n_channels, eos_id, pad_id;
     int32_t encoder_type, n_latents;
-    int32_t dec_ffn, n_experts, moe_top_k;
+    int32_t dec_ffn, n_experts, moe_top_k, moe_fp8;
     int32_t max_batch;              /* segments per call the workspace is sized for */
 } ymt3_config;
 

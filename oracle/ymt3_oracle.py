@@ -237,20 +237,47 @@ def dense_ffn(xn: Tensor, W: Dict[str, Tensor], p: str, bf16: bool) -> Tensor:
     return ff @ W[p + "wo2"].T
 
 
+FP8_MAX = 448.0
+# When a list, moe_ffn appends one (rows,) tensor per call: the gap between the k-th and (k+1)-th router logit.
+# A row whose gap is below the numerical noise can legitimately route to a different expert on the GPU (a discrete
+# change worth ~0.2 in the logits), so parity tests exclude such (row, step) pairs -- the same policy as argmax margins.
+MOE_ROUTER_MARGINS = None
+
+
+def quant_rows_fp8(x: Tensor):
+    """Per-row dynamic e4m3 quantisation: q = fp8(x * (448 / amax)), x ~ q * (amax / 448).  Returns (q as fp32, scale)."""
+    amax = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-12)
+    inv = (FP8_MAX / amax).float()
+    q = (x * inv).to(torch.float8_e4m3fn).float()
+    return q, (amax / FP8_MAX).float()
+
+
 def moe_ffn(xn: Tensor, W: Dict[str, Tensor], p: str, cfg, bf16: bool) -> Tensor:
     """a11 (build-defined; parity unpinned): router softmax -> top-k -> renormalised expert mix.
 
     router logits fp32 from the bf16-rounded normed row; top-k by value, ties to the lower expert
     index; gates = softmax over the selected k logits; each expert is a dense ReLU FFN.
+    moe_fp8: expert weights are stored as OCP e4m3 with one scale per (expert, matrix); the rows entering
+    each expert GEMM are quantised per row (quant_rows_fp8); products accumulate in fp32 and are rescaled
+    by row_scale * weight_scale.  The hidden activations are still rounded to bf16 between the two GEMMs.
     """
     E, k, d, dff = cfg.n_experts, cfg.moe_top_k, cfg.d_model, cfg.d_ff
+    fp8 = bool(getattr(cfg, "moe_fp8", 0))
     logits = xn @ W[p + "router"].T                                    # (..., E)
     # stable top-k with lowest-index tie-break
     order = torch.argsort(-logits, dim=-1, stable=True)[..., :k]
     sel = torch.gather(logits, -1, order)
     gates = torch.softmax(sel, dim=-1)
-    wi = W[p + "wi"].view(E, dff, d)
-    wo = W[p + "wo2"].view(E, d, dff)
+    if MOE_ROUTER_MARGINS is not None:
+        top = torch.topk(logits, k + 1, dim=-1).values
+        MOE_ROUTER_MARGINS.append((top[..., k - 1] - top[..., k]).reshape(-1).clone())
+    if fp8:
+        wi = W[p + "wi_q8"].view(torch.float8_e4m3fn).float().view(E, dff, d)
+        wo = W[p + "wo2_q8"].view(torch.float8_e4m3fn).float().view(E, d, dff)
+        wi_s, wo_s = W[p + "wi_s"], W[p + "wo2_s"]
+    else:
+        wi = W[p + "wi"].view(E, dff, d)
+        wo = W[p + "wo2"].view(E, d, dff)
     out = torch.zeros_like(xn)
     flat_x = xn.reshape(-1, d)
     flat_o = out.reshape(-1, d)
@@ -261,8 +288,15 @@ def moe_ffn(xn: Tensor, W: Dict[str, Tensor], p: str, cfg, bf16: bool) -> Tensor
             rows = (flat_order[:, j] == e).nonzero().flatten()
             if rows.numel() == 0:
                 continue
-            hdd = _r(torch.relu(flat_x[rows] @ wi[e].T), bf16)
-            flat_o[rows] += flat_g[rows, j:j + 1] * (hdd @ wo[e].T)
+            if fp8:
+                xq, xs = quant_rows_fp8(flat_x[rows])
+                hdd = _r(torch.relu((xq @ wi[e].T) * (xs * wi_s[e])), bf16)
+                hq, hs = quant_rows_fp8(hdd)
+                y = (hq @ wo[e].T) * (hs * wo_s[e])
+            else:
+                hdd = _r(torch.relu(flat_x[rows] @ wi[e].T), bf16)
+                y = hdd @ wo[e].T
+            flat_o[rows] += flat_g[rows, j:j + 1] * y
     return flat_o.view_as(xn)
 
 

@@ -55,6 +55,7 @@ class YMT3Config:
     dec_ffn: int = FFN_DENSE          # FFN_MOE for config 5
     n_experts: int = 8
     moe_top_k: int = 2
+    moe_fp8: int = 0                  # 1: expert GEMMs on OCP e4m3 MFMA (per-expert weight scale, per-row activation scale)
 
     @property
     def n_frames(self) -> int:
@@ -92,7 +93,7 @@ class CConfig(ctypes.Structure):
         ("max_decode_len", ctypes.c_int32), ("n_channels", ctypes.c_int32),
         ("eos_id", ctypes.c_int32), ("pad_id", ctypes.c_int32),
         ("encoder_type", ctypes.c_int32), ("n_latents", ctypes.c_int32),
-        ("dec_ffn", ctypes.c_int32), ("n_experts", ctypes.c_int32), ("moe_top_k", ctypes.c_int32),
+        ("dec_ffn", ctypes.c_int32), ("n_experts", ctypes.c_int32), ("moe_top_k", ctypes.c_int32), ("moe_fp8", ctypes.c_int32),
         ("max_batch", ctypes.c_int32),
     ]
 
@@ -119,5 +120,5 @@ def baseline_config(i: int) -> YMT3Config:
     if i == 3:      # 13-channel multi-track decoder, 256 tokens per channel
         return base.with_(n_channels=13, max_decode_len=256, eos_id=-1)
     if i == 4:      # MoE decoder FFN (8 experts)
-        return base.with_(dec_ffn=FFN_MOE, eos_id=-1)
+        return base.with_(dec_ffn=FFN_MOE, moe_fp8=1, eos_id=-1)
     raise IndexError(i)

@@ -127,6 +127,9 @@ struct MoeArgs {
     const bf16_t* router;       // [E][d_model]
     const bf16_t* wi;           // [E][d_ff][d_model]
     const bf16_t* wo;           // [E][d_model][d_ff]
+    const uint8_t* wi_q8; const uint8_t* wo_q8;   // fp8 (OCP e4m3) forms, same shapes
+    const float* wi_s; const float* wo_s;         // [E] dequantisation scales
+    int fp8;
     bf16_t* xn;                 // [R][d_model] normed rows (bf16)
     int* sel; float* gate;      // [R][2] chosen experts and their gates
     int* pair_rank; int* pair_row; float* pair_gate; int* row_pair;   // [2R] pair tables (expert-sorted order q)

@@ -16,7 +16,8 @@
 //                       8-way split-K structure as dec_gemm_kernel, rows gathered through the pair table
 //   moe_combine_kernel  one wave per row: h += y[pair0] + y[pair1]; sum(h^2) for the next norm
 // Expert weights are replicated on every GPU (8 x 2 x 2 MB per layer): the path stays pure data-parallel,
-// no all-to-all.  bf16 MFMA; the fp8 variant BASELINE configs[4] names is not built yet.
+// no all-to-all.  bf16 MFMA by default; moe_fp8 = 1 selects the OCP-e4m3 MFMA form of the expert
+// GEMMs that BASELINE configs[4] names (moe_gemm_fp8_kernel below).
 #include "common.h"
 #include "kernels.h"
 
@@ -181,6 +182,117 @@ __global__ __launch_bounds__(512) void moe_gemm_kernel(MoeArgs a) {
     }
 }
 
+// fp8 (OCP e4m3) form of the grouped expert GEMM (BASELINE configs[4]): weights arrive pre-quantised with one fp32
+// scale per (expert, matrix); the 16 activation rows of the work item are quantised here, per row, with a dynamic scale
+// (amax / 448) -- every workgroup sees its rows over the full K, so the row maximum is an in-workgroup reduction
+// (per-wave partial maxima -> LDS -> 8-way max).  v_mfma_f32_16x16x32_fp8_fp8 accumulates in fp32; the epilogue
+// multiplies by row_scale * weight_scale.  Oracle: oracle/ymt3_oracle.py::moe_ffn (moe_fp8 branch).
+template <int STAGE, int K>
+__global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
+    constexpr int KW = K / 8, KS = KW / 32, PITCH = KW + 16, STRIP = 16 * PITCH;
+    constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;          // bf16 activation rows
+    constexpr int LPRW = KW / 16, RPIW = 64 / LPRW, NIW = 16 / RPIW;         // fp8 weight rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);               // [8][16][16]
+    float* smax = red + 8 * 16 * 16;                           // [8][16] per-wave row maxima
+    float* sinv = smax + 8 * 16;                               // [16] 448 / amax
+    float* sxs = sinv + 16;                                    // [16] amax / 448
+    char* strips = reinterpret_cast<char*>(sxs + 16);
+
+    const int n_nt = (STAGE == 0 ? a.d_ff : a.d_model) / 16;
+    const int item = blockIdx.x / n_nt, nt = blockIdx.x % n_nt;
+    if (item >= *a.n_items) return;
+    const int e = a.item_expert[item], q0 = a.item_pair0[item], cnt = a.item_count[item];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int n0 = nt * 16, N = STAGE == 0 ? a.d_ff : a.d_model;
+    const uint8_t* W = (STAGE == 0 ? a.wi_q8 : a.wo_q8) + (size_t)e * N * K;
+    const float wscale = (STAGE == 0 ? a.wi_s : a.wo_s)[e];
+
+    char* sA = strips + wave * 2 * STRIP;
+    char* sW = sA + STRIP;
+    u32x4 wv[NIW], av[NI];
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int row = i * RPIW + lane / LPRW, ch = lane % LPRW;
+        wv[i] = *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + row) * K + wave * KW + ch * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = i * RPI + lane / LPR, ch = lane % LPR;
+        const int q = q0 + (row < cnt ? row : cnt - 1);
+        const bf16_t* arow = STAGE == 0 ? a.xn + (size_t)a.pair_row[q] * K : a.hidden + (size_t)q * K;
+        av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // per-wave partial row maxima of |x|
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] << 16)));
+            mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] & 0xffff0000u)));
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane % LPR == 0) smax[wave * 16 + i * RPI + lane / LPR] = mx;
+    }
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+        *reinterpret_cast<u32x4*>(sW + (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16) = wv[i];
+    __syncthreads();
+    if (tid < 16) {
+        float mx = smax[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) mx = fmaxf(mx, smax[w * 16 + tid]);
+        mx = fmaxf(mx, 1e-12f);
+        sinv[tid] = 448.0f / mx;
+        sxs[tid] = mx / 448.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = i * RPI + lane / LPR;
+        const float inv = sinv[row];
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][0] << 16) * inv, __uint_as_float(av[i][0] & 0xffff0000u) * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][1] << 16) * inv, __uint_as_float(av[i][1] & 0xffff0000u) * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][2] << 16) * inv, __uint_as_float(av[i][2] & 0xffff0000u) * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][3] << 16) * inv, __uint_as_float(av[i][3] & 0xffff0000u) * inv, hi, true);
+        *reinterpret_cast<int2*>(sA + row * PITCH + (lane % LPR) * 8) = make_int2(lo, hi);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int o = li * PITCH + ks * 32 + g * 8;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(*reinterpret_cast<const long*>(sW + o), *reinterpret_cast<const long*>(sA + o),
+                                                         acc, 0, 0, 0);
+    }
+    *reinterpret_cast<float4*>(red + ((wave * 16 + li) * 16 + g * 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (tid >= 128) return;
+    const int mr = tid >> 3, nq = (tid & 7) * 2;
+    float2 s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+        const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * 16 + nq));
+        s.x += t.x; s.y += t.y;
+    }
+    if (mr >= cnt) return;
+    const int q = q0 + mr;
+    const float sc = sxs[mr] * wscale;
+    s.x *= sc; s.y *= sc;
+    if constexpr (STAGE == 0) {
+        *reinterpret_cast<uint32_t*>(a.hidden + (size_t)q * a.d_ff + n0 + nq) = pack_bf16x2(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f));
+    } else {
+        const float gt = a.pair_gate[q];
+        *reinterpret_cast<float2*>(a.y + (size_t)q * a.d_model + n0 + nq) = make_float2(gt * s.x, gt * s.y);
+    }
+}
+
+template <int K>
+constexpr size_t moe_fp8_lds() { return (size_t)(8 * 16 * 16 + 8 * 16 + 32) * 4 + (size_t)8 * 2 * 16 * (K / 8 + 16); }
+
 __global__ __launch_bounds__(512) void moe_combine_kernel(MoeArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = a.row0 + blockIdx.x * 8 + wave;
@@ -212,7 +324,11 @@ int init_moe_kernels() {
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_lds<0, 512>());
     const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_kernel<1, 2048>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_lds<1, 2048>());
-    return (e0 == hipSuccess && e1 == hipSuccess) ? 0 : -2;
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_fp8_kernel<0, 512>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_fp8_lds<512>());
+    const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_fp8_kernel<1, 2048>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_fp8_lds<2048>());
+    return (e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -2;
 }
 
 // stage: 0 router, 1 plan, 2 expert wi, 3 expert wo, 4 combine
@@ -223,8 +339,14 @@ int launch_moe_stage(int stage, const MoeArgs& a, hipStream_t stream) {
     switch (stage) {
         case 0: moe_router_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a); break;
         case 1: moe_plan_kernel<<<1, 1024, 0, stream>>>(a); break;
-        case 2: moe_gemm_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_lds<0, 512>(), stream>>>(a); break;
-        case 3: moe_gemm_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_lds<1, 2048>(), stream>>>(a); break;
+        case 2:
+            if (a.fp8) moe_gemm_fp8_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_fp8_lds<512>(), stream>>>(a);
+            else moe_gemm_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_lds<0, 512>(), stream>>>(a);
+            break;
+        case 3:
+            if (a.fp8) moe_gemm_fp8_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_fp8_lds<2048>(), stream>>>(a);
+            else moe_gemm_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_lds<1, 2048>(), stream>>>(a);
+            break;
         case 4: moe_combine_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a); break;
         default: return -1;
     }

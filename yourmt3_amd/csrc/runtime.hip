@@ -121,7 +121,7 @@ static int get(ymt3_ctx* c, const std::string& name, uint32_t dtype, T** out, si
     auto it = c->tensors.find(name);
     if (it == c->tensors.end()) FAIL(YMT3_ERR_BLOB, "weight blob has no tensor '%s'", name.c_str());
     if (it->second.dtype != dtype) FAIL(YMT3_ERR_BLOB, "tensor '%s' has dtype %u, expected %u", name.c_str(), it->second.dtype, dtype);
-    const size_t esz = dtype == 1 ? 2 : 4;
+    const size_t esz = dtype == 1 ? 2 : (dtype == 3 ? 1 : 4);
     if (it->second.nbytes < min_elems * esz)
         FAIL(YMT3_ERR_BLOB, "tensor '%s' holds %zu bytes, expected at least %zu", name.c_str(), it->second.nbytes, min_elems * esz);
     *out = reinterpret_cast<T*>(it->second.dev);
@@ -299,7 +299,11 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     for (int l = 0; l < k.n_enc_layers; ++l)
         for (const char* n : enc_names)
             if (!c->tensors.count("enc." + std::to_string(l) + "." + n)) FAIL(YMT3_ERR_BLOB, "missing enc.%d.%s", l, n);
-    const char* dec_names[] = {"ln1", "wqkv", "wo", "ln2", "wq_c", "wo_c", "ln3", "wi", "wo2"};
+    const bool fp8_experts = k.dec_ffn == YMT3_FFN_MOE && k.moe_fp8;
+    std::vector<const char*> dec_names = {"ln1", "wqkv", "wo", "ln2", "wq_c", "wo_c", "ln3"};
+    if (fp8_experts) { dec_names.push_back("wi_q8"); dec_names.push_back("wo2_q8"); dec_names.push_back("wi_s"); dec_names.push_back("wo2_s"); }
+    else { dec_names.push_back("wi"); dec_names.push_back("wo2"); }
+    if (k.dec_ffn == YMT3_FFN_MOE) dec_names.push_back("router");
     for (int l = 0; l < nd; ++l)
         for (const char* n : dec_names)
             if (!c->tensors.count("dec." + std::to_string(l) + "." + n)) FAIL(YMT3_ERR_BLOB, "missing dec.%d.%s", l, n);
@@ -424,7 +428,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     bf16_t* w;
     float* f;
     // every weight of the step up front
-    struct LayerW { float *ln1, *ln2, *ln3; bf16_t *wqkv, *wo, *wq_c, *wo_c, *wi, *wo2, *router; };
+    struct LayerW { float *ln1, *ln2, *ln3; bf16_t *wqkv, *wo, *wq_c, *wo_c, *wi, *wo2, *router; uint8_t *wi_q8, *wo_q8; float *wi_s, *wo_s; };
     std::vector<LayerW> LW(k.n_dec_layers);
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const std::string p = "dec." + std::to_string(l) + ".";
@@ -436,8 +440,16 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         GET(h, p + "wq_c", 1u, &LW[l].wq_c, (size_t)inner * d);
         GET(h, p + "wo_c", 1u, &LW[l].wo_c, (size_t)d * inner);
         const size_t ne = k.dec_ffn == YMT3_FFN_MOE ? (size_t)k.n_experts : 1;
-        GET(h, p + "wi", 1u, &LW[l].wi, ne * k.d_ff * d);
-        GET(h, p + "wo2", 1u, &LW[l].wo2, ne * d * k.d_ff);
+        LW[l].wi = LW[l].wo2 = nullptr; LW[l].wi_q8 = LW[l].wo_q8 = nullptr; LW[l].wi_s = LW[l].wo_s = nullptr;
+        if (k.dec_ffn == YMT3_FFN_MOE && k.moe_fp8) {
+            GET(h, p + "wi_q8", 3u, &LW[l].wi_q8, ne * k.d_ff * d);
+            GET(h, p + "wo2_q8", 3u, &LW[l].wo_q8, ne * d * k.d_ff);
+            GET(h, p + "wi_s", 0u, &LW[l].wi_s, ne);
+            GET(h, p + "wo2_s", 0u, &LW[l].wo_s, ne);
+        } else {
+            GET(h, p + "wi", 1u, &LW[l].wi, ne * k.d_ff * d);
+            GET(h, p + "wo2", 1u, &LW[l].wo2, ne * d * k.d_ff);
+        }
         LW[l].router = nullptr;
         if (k.dec_ffn == YMT3_FFN_MOE) GET(h, p + "router", 1u, &LW[l].router, (size_t)k.n_experts * d);
     }
@@ -476,6 +488,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             MoeArgs mo = h->moe;
             mo.h = h->h_dec; mo.gain = W.ln3; mo.ssq = h->ssq; mo.ssq_stride = h->maxR;
             mo.router = W.router; mo.wi = W.wi; mo.wo = W.wo2; mo.row0 = row0; mo.R = R;
+            mo.wi_q8 = W.wi_q8; mo.wo_q8 = W.wo_q8; mo.wi_s = W.wi_s; mo.wo_s = W.wo_s; mo.fp8 = k.moe_fp8;
             { ProfScope _ps(h, PC_FFN_WI, s); LAUNCH(launch_moe_stage(0, mo, s)); LAUNCH(launch_moe_stage(1, mo, s)); LAUNCH(launch_moe_stage(2, mo, s)); }
             { ProfScope _ps(h, PC_FFN_WO, s); LAUNCH(launch_moe_stage(3, mo, s)); LAUNCH(launch_moe_stage(4, mo, s)); }
         } else {

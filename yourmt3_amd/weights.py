@@ -25,7 +25,8 @@ import torch
 from .config import YMT3Config, ENC_PERCEIVER_TF, FFN_MOE
 
 MAGIC = b"YMT3BLOB"
-DT_F32, DT_BF16, DT_I32 = 0, 1, 2
+DT_F32, DT_BF16, DT_I32, DT_U8 = 0, 1, 2, 3
+FP8_MAX = 448.0                      # OCP e4m3fn largest finite value
 _ENTRY = struct.Struct("<48sII4IQQ")
 
 
@@ -99,8 +100,13 @@ def make_weights(cfg: YMT3Config, seed: int = 1234) -> Dict[str, torch.Tensor]:
         W[p + "ln3"] = gain(d)
         if cfg.dec_ffn == FFN_MOE:
             W[p + "router"] = mat(cfg.n_experts, d, d ** -0.5)
-            W[p + "wi"] = mat(cfg.n_experts * dff, d, d ** -0.5)
-            W[p + "wo2"] = mat(cfg.n_experts * d, dff, dff ** -0.5)
+            wi = mat(cfg.n_experts * dff, d, d ** -0.5)
+            wo2 = mat(cfg.n_experts * d, dff, dff ** -0.5)
+            if getattr(cfg, "moe_fp8", 0):
+                W[p + "wi_q8"], W[p + "wi_s"] = quantize_fp8_per_expert(wi, cfg.n_experts)
+                W[p + "wo2_q8"], W[p + "wo2_s"] = quantize_fp8_per_expert(wo2, cfg.n_experts)
+            else:
+                W[p + "wi"], W[p + "wo2"] = wi, wo2
         else:
             W[p + "wi"] = mat(dff, d, d ** -0.5)
             W[p + "wo2"] = mat(d, dff, dff ** -0.5)
@@ -108,6 +114,16 @@ def make_weights(cfg: YMT3Config, seed: int = 1234) -> Dict[str, torch.Tensor]:
     W["dec.ln_f"] = gain(d)
     W["dec.lm_head"] = mat(V, d, d ** -0.5)
     return W
+
+
+def quantize_fp8_per_expert(w: torch.Tensor, n_experts: int):
+    """[E*rows][cols] fp32 -> (uint8 view of OCP e4m3fn values, [E] fp32 scales): w ~ q * scale[e], |q| <= 448."""
+    we = w.view(n_experts, -1, w.shape[-1]).float()
+    amax = we.abs().amax(dim=(1, 2)).clamp_min(1e-12)
+    scale = (amax / FP8_MAX).float()
+    inv = (FP8_MAX / amax).float()
+    q = (we * inv[:, None, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).reshape(w.shape).contiguous(), scale.contiguous()
 
 
 def _perceiver_weights(cfg, W, g, mat, gain):
@@ -146,6 +162,9 @@ def pack_blob(W: Dict[str, torch.Tensor]) -> bytes:
         if is_bf16_tensor(n):
             raw = f32_to_bf16_bits(t).tobytes()
             dt = DT_BF16
+        elif t.dtype == torch.uint8:
+            raw = t.numpy().tobytes()
+            dt = DT_U8
         elif t.dtype in (torch.int32,):
             raw = t.numpy().astype(np.int32).tobytes()
             dt = DT_I32
@@ -182,6 +201,8 @@ def unpack_blob(blob: bytes) -> Dict[str, torch.Tensor]:
         raw = blob[off:off + nbytes]
         if dt == DT_BF16:
             t = bf16_bits_to_f32(np.frombuffer(raw, dtype=np.uint16)).reshape(shape)
+        elif dt == DT_U8:
+            t = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).reshape(shape)
         elif dt == DT_I32:
             t = torch.from_numpy(np.frombuffer(raw, dtype=np.int32).copy()).reshape(shape)
         else:
