@@ -26,43 +26,77 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int E_MAX = 16;
 
+__device__ __forceinline__ float moe_dpp_sum8(float v) {      // sum over 8 consecutive lanes, DPP only
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+
+// one wave per row.  The normed row goes through a wave-private LDS strip so that lane group e (8 lanes) can take the
+// WHOLE dot product of expert e: all E <= 8 router logits come out of one 3-step DPP reduction instead of E wave-wide
+// ones (E > 8 falls back to a second pass over experts 8..15).
 __global__ __launch_bounds__(512) void moe_router_kernel(MoeArgs a) {
+    __shared__ __attribute__((aligned(16))) float xrow[8][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = a.row0 + blockIdx.x * 8 + wave;
     if (r >= a.row0 + a.R) return;
     constexpr int D = 512;
     float ss = 0.f;
     if (lane < SSQ_TILES) ss = a.ssq[(size_t)lane * a.ssq_stride + r];
-    // fixed order: pairwise tree over the 32 partials (lanes >= 32 contribute 0)
-    ss = wave_sum(ss);
-    const float sc = rsqrtf(ss / (float)D + a.eps);
     const float4* x = reinterpret_cast<const float4*>(a.h + (size_t)r * D);
     const float4* g = reinterpret_cast<const float4*>(a.gain);
-    float xn[8];
+    const float4 v0 = x[lane], v1 = x[lane + 64], g0 = g[lane], g1 = g[lane + 64];
+    // router rows for this lane's expert: lane group `grp` = expert, `sub` = which eighth of the row
+    const int grp = lane >> 3, sub = lane & 7;
+    uint4 wv[8];
+    const bool has_e = grp < a.E;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float4 v = x[lane + 64 * i], gg = g[lane + 64 * i];
+    for (int i = 0; i < 8; ++i)
+        wv[i] = has_e ? *reinterpret_cast<const uint4*>(a.router + (size_t)grp * D + sub * 64 + i * 8) : make_uint4(0, 0, 0, 0);
+    ss = wave_sum(ss);                                          // fixed-order tree over the 32 partials
+    const float sc = rsqrtf(ss / (float)D + a.eps);
+    auto norm4 = [&](const float4& v, const float4& gg, int idx) {
         const bf16_t b0 = f2bf(v.x * sc * gg.x), b1 = f2bf(v.y * sc * gg.y), b2 = f2bf(v.z * sc * gg.z), b3 = f2bf(v.w * sc * gg.w);
-        *reinterpret_cast<uint2*>(a.xn + (size_t)r * D + (lane + 64 * i) * 4) =
+        *reinterpret_cast<uint2*>(a.xn + (size_t)r * D + idx * 4) =
             make_uint2((uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)b2 | ((uint32_t)b3 << 16));
-        xn[4 * i] = bf2f(b0); xn[4 * i + 1] = bf2f(b1); xn[4 * i + 2] = bf2f(b2); xn[4 * i + 3] = bf2f(b3);
+        *reinterpret_cast<float4*>(&xrow[wave][idx * 4]) = make_float4(bf2f(b0), bf2f(b1), bf2f(b2), bf2f(b3));
+    };
+    norm4(v0, g0, lane);
+    norm4(v1, g1, lane + 64);
+    // wave-private strip: LDS executes a wave's accesses in order, no barrier needed
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 xa = *reinterpret_cast<const float4*>(&xrow[wave][sub * 64 + i * 8]);
+        const float4 xb = *reinterpret_cast<const float4*>(&xrow[wave][sub * 64 + i * 8 + 4]);
+        s = fmaf(xa.x, __uint_as_float(wv[i].x << 16), s); s = fmaf(xa.y, __uint_as_float(wv[i].x & 0xffff0000u), s);
+        s = fmaf(xa.z, __uint_as_float(wv[i].y << 16), s); s = fmaf(xa.w, __uint_as_float(wv[i].y & 0xffff0000u), s);
+        s = fmaf(xb.x, __uint_as_float(wv[i].z << 16), s); s = fmaf(xb.y, __uint_as_float(wv[i].z & 0xffff0000u), s);
+        s = fmaf(xb.z, __uint_as_float(wv[i].w << 16), s); s = fmaf(xb.w, __uint_as_float(wv[i].w & 0xffff0000u), s);
     }
+    s = moe_dpp_sum8(s);                                        // every lane of group e now holds logit[e]
     float best = -3.4e38f, second = -3.4e38f;
     int e0 = 0, e1 = 0;
-    for (int e = 0; e < a.E; ++e) {
+    const int ne = a.E < 8 ? a.E : 8;
+    for (int e = 0; e < ne; ++e) {
+        const float le = __shfl(s, e * 8, 64);
+        if (le > best) { second = best; e1 = e0; best = le; e0 = e; }
+        else if (le > second) { second = le; e1 = e; }
+    }
+    for (int e = 8; e < a.E; ++e) {                             // experts 8..15: plain wave-wide dots
         const bf16_t* w = a.router + (size_t)e * D;
-        float s = 0.f;
+        float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const uint2 wv = *reinterpret_cast<const uint2*>(w + (lane + 64 * i) * 4);
-            s = fmaf(xn[4 * i], __uint_as_float(wv.x << 16), s);
-            s = fmaf(xn[4 * i + 1], __uint_as_float(wv.x & 0xffff0000u), s);
-            s = fmaf(xn[4 * i + 2], __uint_as_float(wv.y << 16), s);
-            s = fmaf(xn[4 * i + 3], __uint_as_float(wv.y & 0xffff0000u), s);
+            const uint2 w2 = *reinterpret_cast<const uint2*>(w + (lane + 64 * i) * 4);
+            const float4 xx = *reinterpret_cast<const float4*>(&xrow[wave][(lane + 64 * i) * 4]);
+            t = fmaf(xx.x, __uint_as_float(w2.x << 16), t); t = fmaf(xx.y, __uint_as_float(w2.x & 0xffff0000u), t);
+            t = fmaf(xx.z, __uint_as_float(w2.y << 16), t); t = fmaf(xx.w, __uint_as_float(w2.y & 0xffff0000u), t);
         }
-        s = wave_sum(s);
-        if (s > best) { second = best; e1 = e0; best = s; e0 = e; }
-        else if (s > second) { second = s; e1 = e; }
+        t = wave_sum(t);
+        if (t > best) { second = best; e1 = e0; best = t; e0 = e; }
+        else if (t > second) { second = t; e1 = e; }
     }
     if (lane == 0) {
         const float t = __expf(second - best);
@@ -71,40 +105,49 @@ __global__ __launch_bounds__(512) void moe_router_kernel(MoeArgs a) {
     }
 }
 
-// stable counting sort of pairs (row, slot) by expert; order inside an expert: (row, slot) ascending
+// stable counting sort of the 2R (row, slot) pairs by expert; order inside an expert: (row, slot) ascending.
+// One workgroup; ballots give every pair its rank among the same-expert pairs of its wave, a [chunk][wave][expert]
+// count table in LDS gives the rest -- two barriers per 1024 pairs, no shuffles.
 __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs a) {
-    __shared__ int cnt[E_MAX], off[E_MAX + 1], wsum[16];
+    __shared__ int wcnt[16][E_MAX];       // pairs of expert e in wave w of the current chunk
+    __shared__ int run[E_MAX];            // pairs of expert e in earlier chunks
+    __shared__ int off[E_MAX + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = 2 * a.R;                                     // pairs, p = 2*(r - row0) + slot
-    for (int e = 0; e < a.E; ++e) {
-        int run = 0;                                           // pairs of expert e seen in earlier chunks
-        for (int base = 0; base < P; base += 1024) {
-            const int p = base + tid;
-            const int flag = (p < P && a.sel[2 * a.row0 + p] == e) ? 1 : 0;
-            // block exclusive scan of flag
-            int v = flag;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
-            if (lane == 63) wsum[wave] = v;
-            __syncthreads();
-            int wbase = 0, total = 0;
-            for (int w = 0; w < 16; ++w) { if (w < wave) wbase += wsum[w]; total += wsum[w]; }
-            if (flag) a.pair_rank[a.row0 * 2 + p] = run + wbase + v - 1;      // rank inside its expert
-            run += total;
-            __syncthreads();
-        }
-        if (tid == 0) cnt[e] = run;
-    }
+    if (tid < E_MAX) run[tid] = 0;
     __syncthreads();
+    for (int base = 0; base < P; base += 1024) {
+        const int p = base + tid;
+        const int e = p < P ? a.sel[2 * a.row0 + p] : -1;
+        int rank_in_wave = 0;
+        for (int x = 0; x < a.E; ++x) {
+            const unsigned long long m = __ballot(e == x);
+            if (e == x) rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[wave][x] = __popcll(m);
+        }
+        __syncthreads();
+        if (e >= 0) {
+            int before = run[e];
+            for (int w = 0; w < wave; ++w) before += wcnt[w][e];
+            a.pair_rank[2 * a.row0 + p] = before + rank_in_wave;
+        }
+        __syncthreads();
+        if (tid < a.E) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wcnt[w][tid];
+            run[tid] += t;
+        }
+        __syncthreads();
+    }
     if (tid == 0) {
         int o = 0, items = 0;
         for (int e = 0; e < a.E; ++e) {
             off[e] = o;
-            for (int c = 0; c < cnt[e]; c += 16) {
-                a.item_expert[items] = e; a.item_pair0[items] = o + c; a.item_count[items] = min(16, cnt[e] - c);
+            for (int c = 0; c < run[e]; c += 16) {
+                a.item_expert[items] = e; a.item_pair0[items] = o + c; a.item_count[items] = min(16, run[e] - c);
                 ++items;
             }
-            o += cnt[e];
+            o += run[e];
         }
         off[a.E] = o;
         *a.n_items = items;
@@ -112,7 +155,7 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs a) {
     __syncthreads();
     for (int p = tid; p < P; p += 1024) {
         const int e = a.sel[2 * a.row0 + p];
-        const int q = off[e] + a.pair_rank[a.row0 * 2 + p];    // position in the expert-sorted order
+        const int q = off[e] + a.pair_rank[2 * a.row0 + p];    // position in the expert-sorted order
         a.pair_row[q] = a.row0 + (p >> 1);
         a.pair_gate[q] = a.gate[2 * a.row0 + p];
         a.row_pair[2 * a.row0 + p] = q;
@@ -194,8 +237,8 @@ __global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
     constexpr int LPRW = KW / 16, RPIW = 64 / LPRW, NIW = 16 / RPIW;         // fp8 weight rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);               // [8][16][16]
-    float* smax = red + 8 * 16 * 16;                           // [8][16] per-wave row maxima
-    float* sinv = smax + 8 * 16;                               // [16] 448 / amax
+    unsigned* smax = reinterpret_cast<unsigned*>(red + 8 * 16 * 16);   // [16] row maxima of |x| as float bits (+ pad)
+    float* sinv = reinterpret_cast<float*>(smax) + 8 * 16;     // [16] 448 / amax
     float* sxs = sinv + 16;                                    // [16] amax / 448
     char* strips = reinterpret_cast<char*>(sxs + 16);
 
@@ -204,6 +247,8 @@ __global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
     if (item >= *a.n_items) return;
     const int e = a.item_expert[item], q0 = a.item_pair0[item], cnt = a.item_count[item];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    if (tid < 16) smax[tid] = 0u;
+    __syncthreads();
     const int n0 = nt * 16, N = STAGE == 0 ? a.d_ff : a.d_model;
     const uint8_t* W = (STAGE == 0 ? a.wi_q8 : a.wo_q8) + (size_t)e * N * K;
     const float wscale = (STAGE == 0 ? a.wi_s : a.wo_s)[e];
@@ -224,7 +269,8 @@ __global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
         av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // per-wave partial row maxima of |x|
+    // row maxima of |x|: 8-lane DPP max, then one LDS integer max per (row, 8-lane group) -- |x| >= 0, so the float
+    // bit patterns order like unsigned integers
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         float mx = 0.f;
@@ -233,19 +279,17 @@ __global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
             mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] << 16)));
             mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] & 0xffff0000u)));
         }
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (lane % LPR == 0) smax[wave * 16 + i * RPI + lane / LPR] = mx;
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x141, 0xF, 0xF, true)));
+        if ((lane & 7) == 0) atomicMax(&smax[i * RPI + lane / LPR], __float_as_uint(mx));
     }
 #pragma unroll
     for (int i = 0; i < NIW; ++i)
         *reinterpret_cast<u32x4*>(sW + (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16) = wv[i];
     __syncthreads();
     if (tid < 16) {
-        float mx = smax[tid];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) mx = fmaxf(mx, smax[w * 16 + tid]);
-        mx = fmaxf(mx, 1e-12f);
+        const float mx = fmaxf(__uint_as_float(smax[tid]), 1e-12f);
         sinv[tid] = 448.0f / mx;
         sxs[tid] = mx / 448.0f;
     }
