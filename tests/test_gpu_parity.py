@@ -217,9 +217,9 @@ def test_multichannel_rows_share_the_segment_encoder():
     assert not torch.equal(ref_t[:, 0], ref_t[:, 1])             # channels really differ
 
 
-def test_multichannel_beyond_128_rows_uses_the_64_row_tiles():
+def test_multichannel_beyond_128_rows():
     cfg = YMT3Config(segment_samples=8191, max_decode_len=16, n_channels=13)
-    m = _model(cfg, max_batch=12)                      # 156 rows -> dec_gemm MT = 4 path
+    m = _model(cfg, max_batch=12)                      # 156 rows = 10 row tiles of 16
     a = O.synthetic_audio(12, cfg)
     _, enc = O.encode(a, m.weights, cfg, True)
     ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, 6, True, return_logits=True)
@@ -292,6 +292,140 @@ def test_moe_fp8_expert_gemms_match_oracle():
     m = _moe_case(cfg, 20, 0.08, 8e-3, 0.08, gap=0.02)
     assert m.weights["dec.0.wi_q8"].dtype == torch.uint8 and "dec.0.wi" not in m.weights
     m.close()
+
+
+def test_full_size_properties_baseline_config_1():
+    """BASELINE configs[1] at full size (64 segments, 256 frames, 1024 tokens) is far beyond what the CPU oracle can
+    check in seconds, so this uses size-independent properties: reproducibility, independence of a segment from the rest
+    of the batch, idempotence under teacher forcing with the model's own output, id range, and the EOS->PAD invariant."""
+    from yourmt3_amd.config import baseline_config
+    cfg = baseline_config(1)
+    m = _model(cfg, max_batch=64)
+    a = O.synthetic_audio(64, cfg, seed=21).cuda()
+    t1 = m.inference(a)
+    assert t1.shape == (64, 1, 1024) and t1.dtype == torch.int32
+    assert int(t1.min()) >= 0 and int(t1.max()) < cfg.vocab
+    assert torch.equal(t1, m.inference(a))                                   # bitwise reproducible
+    for i in (0, 37, 63):                                                    # alone == inside the batch
+        assert torch.equal(m.inference(a[i:i + 1])[0], t1[i])
+    enc = m.encode(m.logmel(a))
+    forced = m.decode(enc, 1024, forced=t1)                                  # feeding back its own stream changes nothing
+    assert torch.equal(forced, t1)
+    assert len(torch.unique(t1)) > 200                                       # not a collapsed stream
+    m.close()
+    eos = int(t1[5, 0, 100])
+    m2 = _model(cfg.with_(eos_id=eos), max_batch=64)
+    t2 = m2.inference(a).cpu()
+    m2.close()
+    t1c = t1.cpu()
+    for b in range(64):
+        row = t2[b, 0]
+        hit = (row == eos).nonzero().flatten()
+        if hit.numel():
+            f = int(hit[0])
+            assert torch.equal(row[:f + 1], t1c[b, 0, :f + 1]) and bool((row[f + 1:] == cfg.pad_id).all())
+        else:
+            assert torch.equal(row, t1c[b, 0])
+    assert bool((t2[5, 0, 101:] == cfg.pad_id).all())
+
+
+def test_perceiver_latent_encoder_matches_oracle():
+    """a9 (build-defined spec, parity unpinned w.r.t. the reference): latent array cross-attends to the frames,
+    then latent self-attention blocks; decoder unchanged."""
+    from yourmt3_amd.config import ENC_PERCEIVER_TF
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=32, encoder_type=ENC_PERCEIVER_TF, n_latents=64)
+    m = _model(cfg, max_batch=4)
+    a = O.synthetic_audio(3, cfg)
+    mel_ref, enc_ref = O.encode(a, m.weights, cfg, True)
+    enc = m.encode(m.logmel(a.cuda()))
+    d = (enc.float().cpu() - enc_ref).abs()
+    assert d.max().item() <= 0.0625 and d.mean().item() <= 4e-3
+    t5 = O.encoder_t5(O.input_projection(mel_ref, m.weights, True), m.weights, cfg, True)
+    assert (enc_ref - t5).abs().mean().item() > 0.3                 # it really is a different encoder
+    n = 16
+    ref_t, ref_l = O.greedy_decode(enc_ref, m.weights, cfg, n, True, return_logits=True)
+    got_t, got_l = m.decode(enc_ref.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
+    assert (got_l.cpu() - ref_l).abs().max().item() < 0.06
+    safe = _margin(ref_l) >= TAU
+    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+    m.close()
+    from yourmt3_amd._lib import YMT3Error
+    with pytest.raises(YMT3Error):
+        _model(cfg.with_(n_latents=32))                             # latent length is tied to the frame count
+
+
+def test_two_concurrent_chains_and_unfused_query_path_give_identical_tokens(small):
+    """YMT3_CHAINS / YMT3_NO_FUSEQ are read at create: rows are independent, so any split must be bit-identical;
+    the fused and the separate query projection follow the same rounding points (ids equal where margins allow)."""
+    cfg = SMALL
+    a = O.synthetic_audio(4, cfg, seed=5).cuda()
+    e = small.encode(small.logmel(a))
+    ref = small.decode(e, 40).cpu()
+    os.environ["YMT3_CHAINS"] = "2"
+    try:
+        m2 = _model(cfg)
+    finally:
+        del os.environ["YMT3_CHAINS"]
+    assert torch.equal(m2.decode(e, 40).cpu(), ref)
+    m2.close()
+    os.environ["YMT3_NO_FUSEQ"] = "1"
+    try:
+        m3 = _model(cfg)
+    finally:
+        del os.environ["YMT3_NO_FUSEQ"]
+    t3, l3 = m3.decode(e, 40, forced=ref.cuda(), return_logits=True)
+    t1, l1 = small.decode(e, 40, forced=ref.cuda(), return_logits=True)
+    m3.close()
+    assert (l3 - l1).abs().max().item() < 0.02
+    safe = _margin(l1.cpu()) >= TAU
+    assert torch.equal(t3.cpu()[safe], t1.cpu()[safe])
+
+
+def test_profile_hooks(small):
+    e = small.encode(small.logmel(O.synthetic_audio(2, SMALL).cuda()))
+    prof = small.profile_decode(e, 32, stride=8)
+    assert prof["self_attn"]["launches"] == 4 * SMALL.n_dec_layers and prof["self_attn"]["ms_total"] > 0
+    assert prof["lm_head_gemm"]["launches"] == 4 and prof["unsampled_span"]["launches"] == 3
+    ref = small.decode(e, 16).cpu()
+    from yourmt3_amd import _lib
+    _lib.check(small._lib.ymt3_set_profile_start(small._handle, 8))
+    try:
+        with pytest.raises(_lib.YMT3Error):
+            small.decode(e, SMALL.max_decode_len)              # 8 + 64 > max_decode_len
+        assert small.decode(e, 16).shape == (2, 1, 16)         # runs from position 8; ids are not meaningful
+    finally:
+        _lib.check(small._lib.ymt3_set_profile_start(small._handle, 0))
+    assert torch.equal(small.decode(e, 16).cpu(), ref)
+
+
+def test_bad_blob_and_config_are_rejected():
+    import ctypes
+    from yourmt3_amd import _lib
+    from yourmt3_amd.config import to_c
+    from yourmt3_amd.tables import derived_tables
+    from yourmt3_amd.weights import pack_blob
+    lib = _lib.load()
+    cfg = SMALL
+    W = make_weights(cfg)
+    full = {**W, **derived_tables(W, cfg)}
+    def create(blob, c=cfg):
+        h = ctypes.c_void_p()
+        cc = to_c(c, 2)
+        rc = lib.ymt3_create(ctypes.byref(cc), ctypes.create_string_buffer(blob, len(blob)), len(blob), 0, ctypes.byref(h))
+        if rc == 0:
+            lib.ymt3_destroy(h)
+        return rc, lib.ymt3_last_error().decode()
+    assert create(pack_blob(full))[0] == 0
+    rc, msg = create(b"NOTABLOB" + bytes(64))
+    assert rc == 2 and "magic" in msg
+    rc, msg = create(pack_blob({k: v for k, v in full.items() if k != "dec.3.wo"}))
+    assert rc == 2 and "dec.3.wo" in msg
+    rc, msg = create(pack_blob({k: v for k, v in full.items() if k != "fe.window"}))
+    assert rc == 2 and "fe.window" in msg
+    rc, msg = create(pack_blob(full), cfg.with_(d_kv=32, n_heads=16))
+    assert rc == 4
+    rc, msg = create(pack_blob(full), cfg.with_(segment_samples=8191 + 128))      # 65 frames: not a multiple of 64
+    assert rc == 4 and "n_frames" in msg
 
 
 def test_bad_arguments_raise(small):
