@@ -230,6 +230,24 @@ def test_multichannel_beyond_128_rows():
     assert torch.equal(got_t.cpu()[safe], ref_t[safe])
 
 
+@pytest.mark.parametrize("K", [13, 3, 16])
+def test_multichannel_shared_kv_cross_attention(K):
+    """n_frames in {128, 256, 512} routes the multi-channel cross-attention to the one-workgroup-per-(segment, head)
+    MFMA kernel (mc_cross_attn.hip); same oracle, same tolerances as the per-row kernel."""
+    cfg = YMT3Config(segment_samples=16383, max_decode_len=16, n_channels=K)        # 128 frames
+    m = _model(cfg, max_batch=3)
+    a = O.synthetic_audio(3, cfg)
+    _, enc = O.encode(a, m.weights, cfg, True)
+    n = 10
+    ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, n, True, return_logits=True)
+    got_t, got_l = m.decode(enc.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
+    m.close()
+    d = (got_l.cpu() - ref_l).abs()
+    assert d.max().item() < 0.06 and d.mean().item() < 6e-3
+    safe = _margin(ref_l) >= TAU
+    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+
+
 def test_512_frame_segments():
     cfg = YMT3Config(segment_samples=65535, max_decode_len=16)
     m = _model(cfg, max_batch=2)

@@ -227,9 +227,11 @@ __device__ __forceinline__ float sum8(float v) {
 // computed inside this kernel instead of by a separate skinny GEMM launch.  Its operands (64 weight rows of this
 // head, the residual row, the sum(h^2) partials) are independent of the K/V stream, so they are issued first and
 // the whole projection runs while the K/V loads are in flight: one kernel boundary (~5 us in situ) less per layer.
-template <bool SELF, bool FUSEQ>
-__global__ __launch_bounds__(512, 4) void dec_attn_kernel(DecAttnArgs a) {   // (512, 4): 4 waves / SIMD = two workgroups per CU -> <= 128 VGPRs
-    constexpr int NW = 8;                       // waves per (row, head): 16 waves / CU keep > 12 MB in flight chip-wide
+// NW = waves per (row, head): 8 for up to ~2k workgroups (16 waves per CU keep > 12 MB in flight chip-wide); 2 when there
+// are many more (row, head) pairs than CUs (multi-channel / large batches), where 512-thread workgroups with a few keys
+// each only add dispatch rounds.
+template <bool SELF, bool FUSEQ, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {   // 4 waves / SIMD -> <= 128 VGPRs
     __shared__ float sm[NW], sl[NW], sacc[NW][DKV];
     __shared__ __attribute__((aligned(16))) float xs[FUSEQ ? 512 : 4];
     __shared__ __attribute__((aligned(16))) bf16_t qs[DKV];
@@ -560,9 +562,16 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
 
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
-    if (self_attn) dec_attn_kernel<true, false><<<a.R * a.H, 512, 0, stream>>>(a);
-    else if (a.wq) dec_attn_kernel<false, true><<<a.R * a.H, 512, 0, stream>>>(a);
-    else dec_attn_kernel<false, false><<<a.R * a.H, 512, 0, stream>>>(a);
+    const bool many = a.R * a.H > 2048;
+    if (self_attn) {
+        if (many) dec_attn_kernel<true, false, 2><<<a.R * a.H, 128, 0, stream>>>(a);
+        else dec_attn_kernel<true, false, 8><<<a.R * a.H, 512, 0, stream>>>(a);
+    } else if (a.wq) {
+        dec_attn_kernel<false, true, 8><<<a.R * a.H, 512, 0, stream>>>(a);       // the fused projection maps one thread per d_model element
+    } else {
+        if (many) dec_attn_kernel<false, false, 2><<<a.R * a.H, 128, 0, stream>>>(a);
+        else dec_attn_kernel<false, false, 8><<<a.R * a.H, 512, 0, stream>>>(a);
+    }
     return 0;
 }
 

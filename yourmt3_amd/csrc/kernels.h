@@ -103,6 +103,21 @@ struct DecAttnArgs {
 };
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream);
 
+// multi-channel cross-attention with the query projection fused, one workgroup per (segment, head) (mc_cross_attn.hip)
+struct McCrossArgs {
+    const float* x_f32;         // [R][512] residual stream, row = row0 + seg*n_channels + channel
+    const float* gain;          // [512]
+    const float* ssq; int ssq_stride;
+    const bf16_t* wq;           // [H*64][512]
+    const bf16_t* k;            // [n_seg][H][T][64]
+    const bf16_t* v;
+    bf16_t* out;                // [R][H*64]
+    int row0, n_seg, n_channels, H, T;
+    float eps;
+};
+int init_mc_cross_kernels();
+int launch_mc_cross_attention(const McCrossArgs& a, hipStream_t stream);
+
 struct ArgmaxArgs {
     const float* logits;        // [R][V]
     float* h;                   // [R][d] residual stream to refill with the next embedding

@@ -213,7 +213,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     HIP_TRY(hipSetDevice(c->device));
     int rc = parse_blob(c, blob, nbytes);
     if (rc) return rc;
-    if (init_enc_attn_kernels() || init_decode_kernels() || init_moe_kernels()) FAIL(YMT3_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+    if (init_enc_attn_kernels() || init_decode_kernels() || init_moe_kernels() || init_mc_cross_kernels()) FAIL(YMT3_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
 
     // front-end tables (built by yourmt3_amd/tables.py, carried in the blob)
     const int nfft = k.n_fft;
@@ -474,13 +474,22 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         // the separate skinny GEMM, for A/B measurements)
         t.k = h->ckv + (size_t)(2 * l) * slab; t.v = h->ckv + (size_t)(2 * l + 1) * slab; t.bias = nullptr;
         t.n_keys_const = h->T; t.slab_keys = h->T; t.rows_per_kv = k.n_channels;
-        if (h->fuse_q) {
+        const bool mc = h->fuse_q && k.n_channels >= 2 && k.n_channels <= 16 && (h->T == 128 || h->T == 256 || h->T == 512) &&
+                        row0 % k.n_channels == 0 && R % k.n_channels == 0;
+        if (mc) {
+            // all channels of a segment share its K/V: one workgroup per (segment, head) serves them together
+            McCrossArgs mcx{};
+            mcx.x_f32 = h->h_dec; mcx.gain = W.ln2; mcx.ssq = h->ssq; mcx.ssq_stride = h->maxR; mcx.eps = k.ln_eps;
+            mcx.wq = W.wq_c; mcx.k = t.k + (size_t)(row0 / k.n_channels) * H * h->T * 64; mcx.v = t.v + (size_t)(row0 / k.n_channels) * H * h->T * 64;
+            mcx.out = h->dattn; mcx.row0 = row0; mcx.n_seg = R / k.n_channels; mcx.n_channels = k.n_channels; mcx.H = H; mcx.T = h->T;
+            PLAUNCH(PC_CROSS_ATTN, launch_mc_cross_attention(mcx, s));
+        } else if (h->fuse_q) {
             t.wq = W.wq_c; t.x_f32 = h->h_dec; t.gain = W.ln2; t.ssq = h->ssq; t.ssq_stride = h->maxR; t.eps = k.ln_eps;
         } else {
             a.gain = W.ln2; a.W = W.wq_c; a.N = inner; a.K = d; a.out_bf16 = h->dq;
             PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
         }
-        PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
+        if (!mc) PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
         a.a_bf16 = h->dattn; a.W = W.wo_c; a.N = d; a.K = inner;
         PLAUNCH(PC_CROSS_O, launch_dec_gemm(DG_RESID, a, s));
         // feed-forward block
