@@ -187,7 +187,7 @@ def main():
         result["decode_step_breakdown_us"] = {k: round(1e3 * v, 2) for k, v in step_ms.items()}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(baseline_config(0).with_(eos_id=-1), sample_segments=4, sample_steps=1024)
+        result["cpu_baseline"] = cpu_baseline(baseline_config(0).with_(eos_id=-1), sample_segments=8, sample_steps=1024)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -120,5 +120,33 @@ int main() {
             hipGraphExecDestroy(e); hipGraphDestroy(g);
         }
     }
+    // does it matter that consecutive kernels are DIFFERENT code?  same tiny kernel x1000 vs 5 distinct kernels in rotation
+    {
+        auto run_rot = [&](int nk, const char* name) -> int {
+            hipGraph_t g; hipGraphExec_t e;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < 1000; ++i) {
+                switch (i % nk) {
+                    case 0: k_store<<<128, 512, 0, st>>>(p); break;
+                    case 1: k_load_store<<<128, 512, 0, st>>>(p); break;
+                    case 2: k_load2_store<<<128, 512, 0, st>>>(p); break;
+                    case 3: k_load_sync_store<<<128, 512, 0, st>>>(p); break;
+                    default: k_pull<4><<<128, 512, 0, st>>>(pa, pb, 4 * 512); break;
+                }
+            }
+            CK(hipStreamEndCapture(st, &g));
+            CK(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(e, st)); CK(hipStreamSynchronize(st));
+            auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(e, st));
+            CK(hipStreamSynchronize(st));
+            printf("%-44s %.2f us per kernel\n", name, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 5000.0);
+            hipGraphExecDestroy(e); hipGraphDestroy(g);
+            return 0;
+        };
+        run_rot(1, "rotation of 1 kernel (k_store)");
+        run_rot(2, "rotation of 2 distinct kernels");
+        run_rot(5, "rotation of 5 distinct kernels");
+    }
     return 0;
 }

@@ -61,5 +61,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_tools(force: bool = False) -> str:
+    """tools/ymt3_run: the torch-free C++ host over the C ABI (used by scripts/gpu_pmc.sh).  Rebuilt whenever the
+    header or the library changes -- its `ymt3_config` must match include/ymt3.h."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "ymt3_run.cpp")
+    out = os.path.join(root, "tools", "ymt3_run")
+    if not os.path.exists(src):
+        return ""
+    deps = [src, os.path.join(root, "include", "ymt3.h"), LIB]
+    if force or _stale(out, deps):
+        cmd = [_hipcc(), "-O2", src, "-I" + os.path.join(root, "include"), "-L" + HERE, "-lymt3_hip",
+               "-Wl,-rpath,$ORIGIN/../yourmt3_amd", "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"tools/ymt3_run failed to build:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_tools(force="--force" in sys.argv))
