@@ -1,0 +1,82 @@
+"""Extended parity sweep on the GPU box (beyond the pytest suite): several weight/audio seeds, the real 256-frame shape,
+all encoder / decoder variants, teacher-forced against the CPU oracle.  Writes one JSON record per case.
+Tolerances are the ones in tests/test_gpu_parity.py; `ok` is their conjunction."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from oracle import ymt3_oracle as O  # noqa: E402
+from yourmt3_amd.config import YMT3Config, ENC_PERCEIVER_TF, FFN_MOE  # noqa: E402
+from yourmt3_amd.model import YourMT3  # noqa: E402
+from yourmt3_amd.weights import make_weights  # noqa: E402
+
+TAU = 0.06
+
+
+def case(name, cfg, B, n, wseed, aseed, moe_gap=None):
+    W = make_weights(cfg, seed=wseed)
+    m = YourMT3(cfg, W, max_batch=B)
+    a = O.synthetic_audio(B, cfg, seed=aseed)
+    t0 = time.time()
+    mel_o, enc_o = O.encode(a, W, cfg, True)
+    if moe_gap is not None:
+        O.MOE_ROUTER_MARGINS = []
+    t_o, l_o = O.greedy_decode(enc_o, W, cfg, n, True, return_logits=True)
+    stable = torch.ones(B, cfg.n_channels, n, dtype=torch.bool)
+    if moe_gap is not None:
+        gaps = torch.stack(O.MOE_ROUTER_MARGINS).view(n, cfg.n_dec_layers, B * cfg.n_channels).amin(1).T
+        stable = (gaps >= moe_gap).view(B, cfg.n_channels, n)
+        O.MOE_ROUTER_MARGINS = None
+    cpu_s = time.time() - t0
+    mel = m.logmel(a.cuda())
+    enc = m.encode(mel)
+    t_g, l_g = m.decode(enc_o.bfloat16().cuda(), n, forced=t_o.cuda(), return_logits=True)
+    free = m.decode(enc_o.bfloat16().cuda(), n).cpu()
+    m.close()
+    t_g, l_g = t_g.cpu(), l_g.cpu()
+    top2 = l_o.topk(2, -1).values
+    margin = top2[..., 0] - top2[..., 1]
+    safe = (margin >= TAU) & stable
+    d = (l_g - l_o).abs().amax(-1)
+    prefix_ok = True                                  # free-running stream identical up to its first unsafe step
+    for b in range(B):
+        for k in range(cfg.n_channels):
+            low = ((margin[b, k] < TAU) | ~stable[b, k]).nonzero().flatten()
+            stop = int(low[0]) if low.numel() else n
+            prefix_ok &= bool(torch.equal(free[b, k, :stop], t_o[b, k, :stop]))
+    rec = {"case": name, "B": B, "steps": n, "weight_seed": wseed, "audio_seed": aseed,
+           "logmel_max_abs": (mel.cpu() - mel_o).abs().max().item(),
+           "enc_max_abs": (enc.float().cpu() - enc_o).abs().max().item(),
+           "enc_mean_abs": (enc.float().cpu() - enc_o).abs().mean().item(),
+           "logits_max_abs_stable": d[stable].max().item(), "logits_mean_abs": (l_g - l_o).abs().mean().item(),
+           "safe_fraction": safe.float().mean().item(), "argmax_equal_where_safe": bool(torch.equal(t_g[safe], t_o[safe])),
+           "free_running_prefix_ok": prefix_ok, "oracle_seconds": round(cpu_s, 1)}
+    rec["ok"] = (rec["logmel_max_abs"] < 1e-3 and rec["enc_max_abs"] <= 0.0625
+                 and rec["logits_max_abs_stable"] < (0.08 if moe_gap else 0.06)
+                 and rec["argmax_equal_where_safe"] and rec["free_running_prefix_ok"])
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
+def main():
+    out = []
+    base = YMT3Config(max_decode_len=64)
+    for ws, as_ in ((1234, 0), (7, 11), (99, 5)):
+        out.append(case("t5_enc_256f", base, 6, 48, ws, as_))
+    out.append(case("t5_enc_512f", base.with_(segment_samples=65535), 2, 24, 1234, 3))
+    out.append(case("perceiver_256f", base.with_(encoder_type=ENC_PERCEIVER_TF, n_latents=256), 4, 32, 21, 2))
+    out.append(case("mc13_256f", base.with_(n_channels=13, max_decode_len=32), 3, 20, 1234, 0))
+    out.append(case("mc13_256f_seed2", base.with_(n_channels=13, max_decode_len=32), 2, 20, 5, 9))
+    out.append(case("moe_bf16_256f", base.with_(dec_ffn=FFN_MOE), 4, 32, 1234, 0, moe_gap=0.005))
+    out.append(case("moe_fp8_256f", base.with_(dec_ffn=FFN_MOE, moe_fp8=1), 4, 32, 1234, 0, moe_gap=0.02))
+    print("ALL_OK", all(r["ok"] for r in out))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/extended_parity.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
