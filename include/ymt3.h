@@ -77,6 +77,12 @@ int ymt3_encode(ymt3_handle h, const float* mel_dev, int B, void* enc_dev, void*
 int ymt3_decode_greedy(ymt3_handle h, const void* enc_dev, int B, int n_steps, int32_t* tokens_dev,
                        const int32_t* forced_dev, float* logits_dev, void* stream);
 
+/* Opt-in early stop (first step): with eos_id >= 0 and interval > 0, ymt3_decode_greedy /
+ * ymt3_transcribe_segments check on the host every `interval` steps whether every row has emitted EOS and stop
+ * launching once all have (the remainder of each row is PAD, exactly what the full-length run produces).  This is the
+ * ONLY mode in which a call synchronises the stream.  interval = 0 (default) restores the fully asynchronous loop. */
+int ymt3_set_early_stop(ymt3_handle h, int interval);
+
 /* The whole hot path: audio (B, segment_samples) f32 -> token ids (B, n_channels, n_steps) int32. */
 int ymt3_transcribe_segments(ymt3_handle h, const float* audio_dev, int B, int n_steps,
                              int32_t* tokens_dev, void* stream);

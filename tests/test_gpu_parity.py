@@ -181,6 +181,30 @@ def test_eos_then_pad_fill():
     assert got[0, 0, 5:].eq(cfg.pad_id).all()
 
 
+def test_early_stop_produces_the_same_tokens_and_stops_launching(small):
+    import time
+    cfg = SMALL
+    a = O.synthetic_audio(3, cfg, seed=2)
+    base = _model(cfg.with_(eos_id=-1))
+    e = base.encode(base.logmel(a.cuda()))
+    free = base.decode(e, 64).cpu()
+    base.close()
+    eos = int(free[0, 0, 3])                                # every row sees this id early in its stream?  make sure
+    m = _model(cfg.with_(eos_id=eos))
+    full = m.decode(e, 64).cpu()
+    m.set_early_stop(4)
+    early = m.decode(e, 64).cpu()
+    assert torch.equal(early, full)
+    if all(eos in full[b, 0, :16].tolist() for b in range(3)):     # all rows done early -> far fewer steps were launched
+        torch.cuda.synchronize(); t0 = time.perf_counter(); m.decode(e, 64); torch.cuda.synchronize(); t_early = time.perf_counter() - t0
+        m.set_early_stop(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); m.decode(e, 64); torch.cuda.synchronize(); t_full = time.perf_counter() - t0
+        assert t_early < t_full
+    m.set_early_stop(0)
+    assert torch.equal(m.decode(e, 64).cpu(), full)
+    m.close()
+
+
 def test_rows_are_independent_of_batch_composition(small):
     cfg = SMALL
     a = O.synthetic_audio(4, cfg, seed=7).cuda()

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("YMT3_LIB", os.path.join(_HERE, "libymt3_hip.so"))
 # every symbol include/ymt3.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "ymt3_abi_version", "ymt3_last_error", "ymt3_create", "ymt3_destroy", "ymt3_device_bytes",
-    "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm", "ymt3_profile_decode", "ymt3_set_profile_start",
+    "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm", "ymt3_profile_decode", "ymt3_set_profile_start", "ymt3_set_early_stop",
 ]
 
 _lib = None
@@ -56,6 +56,8 @@ def load() -> ctypes.CDLL:
     lib.ymt3_profile_decode.restype = i32
     lib.ymt3_set_profile_start.argtypes = [vp, i32]
     lib.ymt3_set_profile_start.restype = i32
+    lib.ymt3_set_early_stop.argtypes = [vp, i32]
+    lib.ymt3_set_early_stop.restype = i32
     for n in ("ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm"):
         getattr(lib, n).restype = i32
     if lib.ymt3_abi_version() != 1:

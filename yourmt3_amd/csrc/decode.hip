@@ -487,6 +487,11 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
         if (old == (int)gridDim.x - 1) {
             sh->done_count = 0;
             sh->step = t + 1;
+            if (a.eos_id >= 0) {             // the fence above makes every row's flag visible to this last arriver
+                int n = 0;
+                for (int i = 0; i < (int)gridDim.x; ++i) n += a.finished[a.row0 + i] ? 0 : 1;
+                sh->n_unfinished = n;
+            }
         }
     }
 }
@@ -504,11 +509,17 @@ __global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_ch
         sh->step = step0;
         sh->step0 = step0;
         sh->done_count = 0;
+        sh->n_unfinished = a.R;
         sh->n_steps = n_steps;
         sh->tokens_out = tokens_out;
         sh->forced = forced;
         sh->logits_out = logits_out;
     }
+}
+
+__global__ void pad_tail_kernel(int32_t* tokens_out, int row0, int n_steps, int from, int pad_id) {
+    int32_t* row = tokens_out + (size_t)(row0 + blockIdx.x) * n_steps;
+    for (int i = from + threadIdx.x; i < n_steps; i += blockDim.x) row[i] = pad_id;
 }
 
 template <int MODE, int K>
@@ -585,5 +596,11 @@ int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int step0
                        float* logits_out, hipStream_t stream) {
     if (a.R <= 0) return 0;
     decode_init_kernel<<<a.R, 256, 0, stream>>>(a, n_chains, n_steps, step0, tokens_out, forced, logits_out);
+    return 0;
+}
+
+int launch_pad_tail(int32_t* tokens_out, int row0, int R, int n_steps, int from, int pad_id, hipStream_t stream) {
+    if (R <= 0 || from >= n_steps) return 0;
+    pad_tail_kernel<<<R, 256, 0, stream>>>(tokens_out, row0, n_steps, from, pad_id);
     return 0;
 }

@@ -55,6 +55,8 @@ struct DecodeShared {           // device-resident loop state, read by every dec
     int done_count;             // ticket counter of the argmax kernel
     int n_steps;                // row stride of tokens_out / forced / logits_out
     int step0;                  // first position of this call (0 except under ymt3_set_profile_start)
+    int n_unfinished;           // rows of this chain that have not emitted EOS yet (maintained when eos_id >= 0)
+    int pad1;
     int32_t* tokens_out;        // [R][n_steps]
     const int32_t* forced;      // [R][n_steps] or null
     float* logits_out;          // [R][n_steps][V] or null
@@ -130,6 +132,8 @@ struct ArgmaxArgs {
     int row0, R, V, d, n_channels, eos_id, pad_id;
 };
 int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream);
+// tokens_out[r][from .. n_steps) = pad for rows [row0, row0 + R): the tail of a decode that stopped early
+int launch_pad_tail(int32_t* tokens_out, int row0, int R, int n_steps, int from, int pad_id, hipStream_t stream);
 // all rows: h[r] = embed[pad] (+ chan_embed), finished = 0; a.shared[0..n_chains) reset
 int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int step0, int32_t* tokens_out, const int32_t* forced,
                        float* logits_out, hipStream_t stream);

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -89,6 +90,8 @@ struct ymt3_ctx {
     bool prof_on = false;
     size_t prof_span_idx = 0;
     bool prof_span_open = false;
+    int early_stop_interval = 0;            // ymt3_set_early_stop: host checks `n_unfinished` every N steps (0 = never)
+    int* host_flag = nullptr;               // pinned, for that check
     int prof_step0 = 0;                     // ymt3_set_profile_start: decode positions begin here (measurement only)
     std::vector<hipEvent_t> prof_ev;        // pairs
     std::vector<int> prof_cls;
@@ -183,6 +186,7 @@ extern "C" void ymt3_destroy(ymt3_handle h) {
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->host_flag) (void)hipHostFree(h->host_flag);
     for (int i = 0; i < 8; ++i) {
         if (h->chain_stream[i]) (void)hipStreamDestroy(h->chain_stream[i]);
         if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
@@ -584,7 +588,22 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
             }
             exec[c] = sg.exec;
         }
-        if (n_chains == 1) {
+        if (n_chains == 1 && h->early_stop_interval > 0 && k.eos_id >= 0 && !forced) {
+            // opt-in (ymt3_set_early_stop): every `interval` steps the host reads how many rows are still decoding and
+            // stops launching once none is; the rest of every row is PAD by the EOS fill rule.  This path synchronises
+            // the stream (the only one that does); with forced tokens the trajectory is fixed, so it is not used.
+            int t = 0;
+            while (t < n_steps) {
+                const int chunk = std::min(h->early_stop_interval, n_steps - t);
+                for (int i = 0; i < chunk; ++i) HIP_TRY(hipGraphLaunch(exec[0], s));
+                t += chunk;
+                if (t >= n_steps) break;
+                HIP_TRY(hipMemcpyAsync(h->host_flag, &h->shared->n_unfinished, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (*h->host_flag == 0) break;
+            }
+            LAUNCH(launch_pad_tail(tokens, 0, R, n_steps, t, k.pad_id, s));
+        } else if (n_chains == 1) {
             for (int t = 0; t < n_steps; ++t) HIP_TRY(hipGraphLaunch(exec[0], s));
         } else {
             // fork: every chain stream waits for the cross-KV GEMM + init on the caller's stream
@@ -667,5 +686,14 @@ extern "C" int ymt3_set_profile_start(ymt3_handle h, int step0) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");
     if (step0 < 0 || step0 >= h->cfg.max_decode_len) FAIL(YMT3_ERR_ARG, "step0=%d outside [0, %d)", step0, h->cfg.max_decode_len);
     h->prof_step0 = step0;
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_set_early_stop(ymt3_handle h, int interval) {
+    if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (interval < 0) FAIL(YMT3_ERR_ARG, "interval must be >= 0");
+    HIP_TRY(hipSetDevice(h->device));
+    if (interval > 0 && !h->host_flag) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_flag), sizeof(int), hipHostMallocDefault));
+    h->early_stop_interval = interval;
     return YMT3_OK;
 }

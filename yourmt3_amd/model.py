@@ -68,6 +68,10 @@ class YourMT3:
             raise ValueError(f"batch {audio.shape[0]} exceeds max_batch {self.max_batch}")
         return audio.to(self.device, torch.float32).contiguous()
 
+    def set_early_stop(self, interval: int) -> None:
+        """Check every `interval` steps whether all rows have emitted EOS and stop decoding once they have (0 = off)."""
+        _lib.check(self._lib.ymt3_set_early_stop(self._handle, int(interval)))
+
     # ------------------------------------------------------------------ stages (C ABI, 1:1)
     def logmel(self, audio: torch.Tensor) -> torch.Tensor:
         a = self._audio2d(audio)
