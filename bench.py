@@ -24,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from yourmt3_amd.audio import synthetic_segments  # noqa: E402
 from yourmt3_amd.config import baseline_config  # noqa: E402
 from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens  # noqa: E402
 from yourmt3_amd.model import YourMT3  # noqa: E402
@@ -32,14 +33,8 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 
 
 def synthetic_audio(n: int, cfg, seed: int, device) -> torch.Tensor:
-    """(n, S) fp32: N(0, 0.1^2) clipped to +-1 plus a tone pair -- same recipe as the oracle's fixture audio."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    S = cfg.segment_samples
-    noise = (0.1 * torch.randn(n, S, generator=g)).clamp(-1, 1)
-    t = torch.arange(S, dtype=torch.float64) / cfg.sample_rate
-    f0 = 220.0 * (1.0 + 0.03 * torch.arange(n, dtype=torch.float64))[:, None]
-    tone = 0.3 * torch.sin(2 * torch.pi * f0 * t) + 0.15 * torch.sin(4 * torch.pi * f0 * t)
-    return (noise + tone.float()).clamp(-1, 1).contiguous().to(device)
+    """(n, S) fp32 synthetic segments (yourmt3_amd.audio.synthetic_segments)."""
+    return torch.from_numpy(synthetic_segments(n, cfg.segment_samples, cfg.sample_rate, seed)).to(device)
 
 
 def self_attn_algorithmic_bytes(cfg, rows: int, t: int) -> int:
@@ -187,7 +182,7 @@ def main():
         result["decode_step_breakdown_us"] = {k: round(1e3 * v, 2) for k, v in step_ms.items()}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(baseline_config(0).with_(eos_id=-1), sample_segments=8, sample_steps=1024)
+        result["cpu_baseline"] = cpu_baseline(baseline_config(0).with_(eos_id=-1), sample_segments=16, sample_steps=1024)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -4,11 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from yourmt3_amd.config import baseline_config
 from yourmt3_amd.model import YourMT3
-from oracle import ymt3_oracle as O
+from yourmt3_amd.audio import synthetic_segments
 
 def throughput(cfg, B, L, reps=2):
     m = YourMT3(cfg, max_batch=B)
-    a = O.synthetic_audio(B, cfg).cuda()
+    a = torch.from_numpy(synthetic_segments(B, cfg.segment_samples)).cuda()
     m.inference(a, max_token_length=L); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps): m.inference(a, max_token_length=L)

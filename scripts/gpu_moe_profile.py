@@ -2,10 +2,10 @@ import sys, time; sys.path.insert(0, "/root/repo")
 import torch
 from yourmt3_amd.config import baseline_config
 from yourmt3_amd.model import YourMT3
-from oracle import ymt3_oracle as O
+from yourmt3_amd.audio import synthetic_segments
 cfg = baseline_config(4)
 m = YourMT3(cfg, max_batch=64)
-a = O.synthetic_audio(64, cfg).cuda()
+a = torch.from_numpy(synthetic_segments(64, cfg.segment_samples)).cuda()
 m.inference(a, max_token_length=256); torch.cuda.synchronize()
 t0 = time.perf_counter(); m.inference(a, max_token_length=256); torch.cuda.synchronize()
 print("ms per 256 steps", 1e3 * (time.perf_counter() - t0))

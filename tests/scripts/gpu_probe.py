@@ -1,6 +1,6 @@
 """Exploratory parity probe on the GPU box (not a test): prints max diffs per stage vs the oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yourmt3_amd.config import YMT3Config
 from yourmt3_amd.model import YourMT3

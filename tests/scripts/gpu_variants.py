@@ -1,7 +1,7 @@
 """Secondary shapes on the GPU box: 512-frame segments (S=65535) and the 13-channel decoder (config 4 shape).
 Parity (teacher-forced, short) + throughput.  Not the headline metric."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yourmt3_amd.config import YMT3Config, baseline_config
 from yourmt3_amd.model import YourMT3

@@ -2,7 +2,7 @@
 
 The reference tree holds no fixtures (parity unpinned), so these vectors are produced by
 this build's own oracle, which tests/test_oracle_vs_thirdparty.py pins against torch.stft and HF T5.
-Run:  python scripts/make_golden.py      (CPU only, ~1 min)
+Run:  python tests/scripts/make_golden.py      (CPU only, ~1 min)
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import ymt3_oracle as O                     # noqa: E402
 from yourmt3_amd.config import YMT3Config               # noqa: E402

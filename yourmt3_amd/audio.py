@@ -41,3 +41,14 @@ def slice_padded_array(x: np.ndarray, slice_length: int, pad: bool = True) -> np
         seg = x[i * slice_length:(i + 1) * slice_length]
         out[i, 0, :seg.shape[0]] = seg
     return out
+
+
+def synthetic_segments(n: int, segment_samples: int, sample_rate: int = 16000, seed: int = 0) -> np.ndarray:
+    """(n, segment_samples) float32 test audio: N(0, 0.1^2) clipped to +-1 plus a tone pair per segment
+    (SURVEY.md section 8d synthetic input); used by bench.py and the measurement scripts."""
+    rng = np.random.default_rng(seed)
+    noise = np.clip(0.1 * rng.standard_normal((n, segment_samples)), -1, 1)
+    t = np.arange(segment_samples, dtype=np.float64) / sample_rate
+    f0 = 220.0 * (1.0 + 0.03 * np.arange(n, dtype=np.float64))[:, None]
+    tone = 0.3 * np.sin(2 * np.pi * f0 * t) + 0.15 * np.sin(4 * np.pi * f0 * t)
+    return np.clip(noise + tone, -1, 1).astype(np.float32)
