@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
             else if (tok == a.eos_id) a.finished[r] = 1;
         }
         sh->tokens_out[(size_t)r * n_steps + col] = tok;
-        s_feed = sh->forced ? sh->forced[(size_t)r * n_steps + col] : tok;
+        int feed = sh->forced ? sh->forced[(size_t)r * n_steps + col] : tok;
+        s_feed = feed < 0 ? 0 : (feed >= a.V ? a.V - 1 : feed);       // caller-supplied ids must not index outside the table
     }
     __syncthreads();
     const int feed = s_feed;

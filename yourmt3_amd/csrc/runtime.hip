@@ -212,6 +212,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     c->maxB = k.max_batch;
     c->maxR = k.max_batch * k.n_channels;
     if (c->T % 64) FAIL(YMT3_ERR_UNSUPPORTED, "n_frames must be a multiple of 64 (got %d)", c->T);
+    if (k.segment_samples <= k.n_fft / 2) FAIL(YMT3_ERR_UNSUPPORTED, "segment_samples must exceed n_fft/2 (reflect padding)");
+    if (k.pad_id < 0 || k.pad_id >= k.vocab || k.eos_id >= k.vocab) FAIL(YMT3_ERR_ARG, "pad_id / eos_id outside the vocabulary");
     if (k.vocab % 16 || k.d_ff % 128) FAIL(YMT3_ERR_UNSUPPORTED, "vocab %% 16 and d_ff %% 128 must be 0");
 
     HIP_TRY(hipSetDevice(c->device));

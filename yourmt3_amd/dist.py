@@ -21,7 +21,10 @@ def init_distributed(n_gpus_hint: int = 1) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # YMT3_DIST_BACKEND=gloo lets several ranks rehearse on ONE GPU (RCCL refuses duplicate devices)
+        backend = os.environ.get("YMT3_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local_rank %= max(1, torch.cuda.device_count())
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank)
@@ -57,7 +60,12 @@ def all_gather_tokens(tokens: torch.Tensor, world: int, n_segments: int | None =
         pad = torch.zeros(bmax - b, K, L, dtype=tokens.dtype, device=tokens.device)
         tokens = torch.cat([tokens, pad], 0)
     out = torch.empty(world * bmax, K, L, dtype=tokens.dtype, device=tokens.device)
-    dist.all_gather_into_tensor(out, tokens.contiguous())
+    if dist.get_backend() == "gloo" and tokens.is_cuda:      # rehearsal on one GPU: gloo gathers through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, tokens.contiguous().cpu())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, tokens.contiguous())
     if all(s == bmax for s in sizes):
         return out
     return torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], 0)
