@@ -16,7 +16,8 @@
  * Conventions
  *   - every pointer named *_dev is DEVICE memory on the handle's GPU, owned by the caller;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all calls are
- *     asynchronous with respect to the host and never synchronise the device;
+ *     asynchronous with respect to the host and never synchronise the device (two documented exceptions, both
+ *     opt-in: ymt3_set_early_stop and the ymt3_profile_decode measurement hook);
  *   - the library owns weights, KV caches and scratch inside the handle; nothing is
  *     allocated after ymt3_create();
  *   - return value: 0 = ok, non-zero = error; the message is in ymt3_last_error()

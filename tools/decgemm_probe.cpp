@@ -65,6 +65,12 @@ int main() {
         t.slab_keys = L; t.rows_per_kv = 1; t.n_keys_const = 0;
         timeit(nm, [&](int i) { t.k = kc + (size_t)(i % NL) * (cache / 2); t.v = vc + (size_t)(i % NL) * (cache / 2); launch_dec_attention(true, t, st); }, st, 120);
     }
+    for (int step : {255, 511, 1023}) {
+        hs.step = step; CK(hipMemcpy(sh, &hs, sizeof(hs), hipMemcpyHostToDevice));
+        char nm[96]; snprintf(nm, 96, "self-attn t=%d (SAME layer cache every launch)", step);
+        t.slab_keys = L; t.rows_per_kv = 1; t.n_keys_const = 0;
+        timeit(nm, [&](int) { t.k = kc; t.v = vc; launch_dec_attention(true, t, st); }, st, 120);
+    }
     t.k = ck; t.v = ck + (size_t)R * H * T * 64; t.slab_keys = T; t.n_keys_const = T; t.bias = nullptr;
     timeit("cross-attn T=256 (same slabs)", [&](int) { launch_dec_attention(false, t, st); }, st, 200);
     // interaction between consecutive kernels: pairs and the whole 8-kernel layer sequence, rotating over 6 layers

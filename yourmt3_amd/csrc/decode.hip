@@ -5,17 +5,18 @@
 // the per-step `.max()==0` host sync of TP: generation/utils.py:2936-2937 becomes device state).
 //
 //  dec_gemm_kernel      skinny GEMM, R = segments x channels rows (64..832) against a [N][K] bf16
-//                       weight that is streamed exactly once per 64-row tile: one workgroup per 16
-//                       output columns, eight waves split K, all fragments go straight from global
-//                       memory to MFMA operand registers (each element is used by one wave), partial
-//                       tiles are summed through LDS in a fixed order (bitwise reproducible; no float
-//                       atomics).  NORM modes apply the T5 RMS norm (TP: modeling_t5.py:50-72) to the
-//                       fp32 residual rows while building the fragments; the epilogues fuse KV-cache
-//                       append (TP: cache_utils.py:144-145), ReLU, residual add + sum(h^2) partials.
+//                       weight: one workgroup per 16 rows x 16 output columns, eight waves split K, each
+//                       wave pulls its K-slice of both operands with whole-line coalesced loads (all in
+//                       flight at once), parks them in a wave-private LDS strip and reads MFMA fragments
+//                       back; partial tiles are summed through LDS in a fixed order (bitwise reproducible;
+//                       no float atomics).  NORM modes apply the T5 RMS norm (TP: modeling_t5.py:50-72)
+//                       with the row's sum(h^2) carried between kernels as partials; the epilogues fuse
+//                       KV-cache append (TP: cache_utils.py:144-145), ReLU, residual add + sum(h^2) partials.
 //  dec_attn_kernel      one (row, head) per workgroup; K/V slabs streamed HBM -> registers with 16-byte
-//                       coalesced loads, 8 in flight per lane; online softmax per lane group, merged by
-//                       shuffles and one LDS pass.  Self-attention adds the unidirectional relative
-//                       position bias by distance (TP: modeling_t5.py:264-279); cross-attention has none.
+//                       coalesced loads, 8-12 in flight per lane; online softmax per 8-lane group (DPP sums),
+//                       merged by shuffles and one LDS pass.  Self-attention adds the unidirectional relative
+//                       position bias by distance (TP: modeling_t5.py:264-279); cross-attention has none and
+//                       computes its own query projection (FUSEQ) while its K/V loads are in flight.
 //  argmax_embed_kernel  fp32 argmax (first index wins ties, TP: utils.py:2925), EOS -> PAD fill
 //                       (:2928-2929), token store, next-token embedding gather into the residual
 //                       stream, and the step counter advance by the last workgroup to finish.
