@@ -13,7 +13,7 @@ struct FrontendTables {
     const int* mel_len;       // [n_mels] bins in each triangle
     const int* mel_off;       // [n_mels] offset into mel_w
     const float* mel_w;       // concatenated triangle weights
-    int n_fft, hop, n_mels, n_samples, n_frames;
+    int n_fft, hop, n_mels, n_samples, n_frames, n_mel_w;
     float log_floor;
 };
 int launch_logmel(const FrontendTables& t, const float* audio, float* mel, int B, hipStream_t stream);

@@ -231,6 +231,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     GET(c, "fe.mel_len", 2u, const_cast<int**>(&fe.mel_len), (size_t)k.n_mels);
     GET(c, "fe.mel_off", 2u, const_cast<int**>(&fe.mel_off), (size_t)k.n_mels);
     GET(c, "fe.mel_w", 0u, const_cast<float**>(&fe.mel_w), 1);
+    fe.n_mel_w = (int)(c->tensors["fe.mel_w"].nbytes / 4);
     fe.n_fft = nfft; fe.hop = k.hop; fe.n_mels = k.n_mels; fe.n_samples = k.segment_samples;
     fe.n_frames = c->T; fe.log_floor = k.log_floor;
     if (nfft != 2048 && nfft != 512) FAIL(YMT3_ERR_UNSUPPORTED, "n_fft must be 2048 or 512");
