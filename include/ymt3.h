@@ -66,6 +66,18 @@ void ymt3_destroy(ymt3_handle h);
 /* Bytes of device memory held by the handle (weights + caches + scratch). */
 size_t ymt3_device_bytes(ymt3_handle h);
 
+/* The step before the path: interleaved PCM on the device, (n_frames, n_channels)
+ * int16 or f32 at any integer sample rate -> mono mix -> polyphase Kaiser-windowed-sinc resample to cfg.sample_rate
+ * (the filter and alignment of scipy.signal.resample_poly) -> (n_segments, segment_samples) f32, zero padded: the
+ * buffer ymt3_logmel / ymt3_transcribe_segments read.  ymt3_ingest_plan is host arithmetic only (how many samples
+ * and segments n_frames become).  The first ymt3_ingest call for a new rate pair designs the filter and uploads
+ * <= 2 MB synchronously (rate pairs whose reduced ratio exceeds 16384 are rejected); later calls allocate nothing and are asynchronous on `stream`. */
+#define YMT3_PCM_S16 0
+#define YMT3_PCM_F32 1
+int ymt3_ingest_plan(ymt3_handle h, int64_t n_frames, int sample_rate_in, int64_t* n_samples_out, int* n_segments);
+int ymt3_ingest(ymt3_handle h, const void* pcm_dev, int pcm_format, int64_t n_frames, int n_channels,
+                int sample_rate_in, float* segments_dev, int n_segments, void* stream);
+
 /* a1+a2: audio (B, segment_samples) f32 -> log-mel (B, n_frames, n_mels) f32. */
 int ymt3_logmel(ymt3_handle h, const float* audio_dev, int B, float* mel_dev, void* stream);
 

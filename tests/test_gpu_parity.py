@@ -501,3 +501,38 @@ def test_against_golden_fixture(name, cfg):
     free = m.decode(enc_ref.bfloat16().cuda(), n).cpu()
     _check_stream_prefix(free, ref_t, margin)
     m.close()
+
+
+# ---------------------------------------------------------------------------------------------- audio ingest (8f rank 2)
+# Tolerance: fp32 accumulation of <= 64 fp32 taps against the oracle's float64 accumulation of the same fp32 taps and
+# samples: abs 5e-6 on unit-scale audio (observed ~5e-7).  Zero padding and segment layout are exact.
+@pytest.mark.parametrize("sr,n,ch,dtype", [(44100, 100000, 2, np.int16), (48000, 70001, 1, np.float32), (8000, 20000, 1, np.int16),
+                                           (22050, 30000, 3, np.float32), (16000, 20000, 2, np.int16), (44100, 37, 2, np.int16)])
+def test_ingest_matches_oracle(small, sr, n, ch, dtype):
+    from oracle import ingest_oracle as IO
+    rng = np.random.default_rng(sr + n)
+    t = np.arange(n)[:, None] / sr
+    x = 0.4 * np.sin(2 * np.pi * 440.0 * (1 + np.arange(ch)[None, :]) * t) + 0.1 * rng.standard_normal((n, ch))
+    pcm = (np.clip(x, -1, 1) * 32767).astype(np.int16) if dtype == np.int16 else x.astype(np.float32)
+    ref = IO.ingest(pcm, sr, SMALL.sample_rate, SMALL.segment_samples)
+    got = small.ingest(torch.from_numpy(pcm), sr)
+    assert got.shape == (ref.shape[0], 1, SMALL.segment_samples) and got.dtype == torch.float32
+    g = got.cpu().numpy()[:, 0]
+    assert np.abs(g - ref).max() < 5e-6
+    n_out = small.last_ingest_samples
+    assert n_out == -(-n * 16000 // sr) and np.all(g.reshape(-1)[n_out:] == 0)
+
+
+def test_ingest_edges_and_errors(small):
+    from yourmt3_amd._lib import YMT3Error
+    empty = small.ingest(torch.zeros(0, 2, dtype=torch.int16), 44100)
+    assert empty.shape == (1, 1, SMALL.segment_samples) and float(empty.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        small.ingest(torch.zeros(10, 1, dtype=torch.float64), 16000)
+    with pytest.raises(YMT3Error):
+        small.ingest(torch.zeros(10, 1, dtype=torch.int16), 0)
+    with pytest.raises(YMT3Error):                                       # 16000/44101 are coprime: an 882 021-tap filter
+        small.ingest(torch.zeros(10, 1, dtype=torch.int16), 44101)
+    # exact multiple of the segment length: no extra padded segment
+    seg = small.ingest(torch.ones(2 * SMALL.segment_samples, dtype=torch.float32), 16000)
+    assert seg.shape[0] == 2 and float((seg - 1).abs().max()) == 0.0

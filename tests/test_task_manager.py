@@ -176,6 +176,11 @@ class _FakeModel:
     def __init__(self, cfg, rows):
         self.cfg, self.rows, self.calls = cfg, rows, []
 
+    def ingest(self, pcm, sample_rate):
+        x = resample(pcm.numpy().reshape(pcm.shape[0], -1).mean(axis=1), sample_rate, self.cfg.sample_rate)
+        self.last_ingest_samples = x.shape[0]
+        return slice_padded_array(x, self.cfg.segment_samples)
+
     def inference_file(self, bsz, segments, max_token_length=None):
         self.calls.append((bsz, tuple(segments.shape), max_token_length))
         return [self.rows[i:i + bsz] for i in range(0, self.rows.shape[0], bsz)]

@@ -9,6 +9,23 @@ from typing import Tuple
 import numpy as np
 
 
+def load_wav_pcm(path: str) -> Tuple[np.ndarray, int]:
+    """WAV file -> ((n_frames, n_channels) int16 or float32 PCM exactly as stored, sample rate): the host does file
+    IO only; mixing, resampling and slicing happen on the device (YourMT3.ingest)."""
+    with wave.open(path, "rb") as w:
+        sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if width == 2:
+        x = np.frombuffer(raw, dtype="<i2")
+    elif width == 4:
+        x = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif width == 1:
+        x = ((np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0).astype(np.float32)
+    else:
+        raise ValueError(f"unsupported sample width {width}")
+    return x.reshape(-1, nch), sr
+
+
 def load_wav(path: str) -> Tuple[np.ndarray, int]:
     with wave.open(path, "rb") as w:
         sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libymt3_hip.so")
-SOURCES = ["runtime.hip", "frontend.hip", "gemm.hip", "norm.hip", "enc_attn.hip", "decode.hip", "moe.hip", "mc_cross_attn.hip"]
+SOURCES = ["runtime.hip", "frontend.hip", "gemm.hip", "norm.hip", "enc_attn.hip", "decode.hip", "moe.hip", "mc_cross_attn.hip", "ingest.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "ymt3.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 

@@ -18,6 +18,16 @@ struct FrontendTables {
 };
 int launch_logmel(const FrontendTables& t, const float* audio, float* mel, int B, hipStream_t stream);
 
+// ---------------------------------------------------------------- audio ingest (ingest.hip)
+struct IngestArgs {
+    const void* pcm;          // [n_in][n_channels] interleaved int16 or fp32
+    const float* taps;        // [up][Jp] polyphase rows of the low-pass, zero padded beyond J
+    float* out;               // [n_total] = (n_seg, segment_samples), zero beyond n_out
+    long long n_in, n_out, n_total, r;   // r: output alignment offset (n_pre_remove of resample_poly)
+    int up, down, J, Jp, n_channels, s16, window;   // window: LDS floats per workgroup
+};
+int launch_ingest(const IngestArgs& a, hipStream_t stream);
+
 // ---------------------------------------------------------------- dense GEMM (gemm.hip)
 // C[M][N] (+)= A[M][K] (bf16, row stride lda) * W[N][K]^T (bf16, row stride ldw), fp32 accumulate.
 enum GemmEpilogue {

@@ -5,6 +5,7 @@
 // decode.hip.  There is no CPU fallback: a missing device, tensor or unsupported shape is an error.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +96,9 @@ struct ymt3_ctx {
     int prof_step0 = 0;                     // ymt3_set_profile_start: decode positions begin here (measurement only)
     std::vector<hipEvent_t> prof_ev;        // pairs
     std::vector<int> prof_cls;
+    // ymt3_ingest: polyphase low-pass per (up, down), built on first use
+    struct Resampler { float* taps = nullptr; int up = 1, down = 1, J = 1, Jp = 4, window = 0; long long r = 0; };
+    std::map<std::pair<int, int>, Resampler> resamplers;
 };
 
 enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_COUNT };
@@ -689,6 +693,106 @@ extern "C" int ymt3_set_profile_start(ymt3_handle h, int step0) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");
     if (step0 < 0 || step0 >= h->cfg.max_decode_len) FAIL(YMT3_ERR_ARG, "step0=%d outside [0, %d)", step0, h->cfg.max_decode_len);
     h->prof_step0 = step0;
+    return YMT3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Audio ingest.  Filter design on the host, in double: the Kaiser(5.0) windowed-sinc
+// low-pass and the alignment of TP: scipy/signal/_signaltools.py resample_poly (restated in oracle/ingest_oracle.py).
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 500; ++k) {
+        term *= x / (2.0 * k);
+        const double t2 = term * term;
+        sum += t2;
+        if (t2 < 1e-20 * sum) break;
+    }
+    return sum;
+}
+
+static long long gcd_ll(long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; }
+
+static int get_resampler(ymt3_ctx* c, int sr_in, const ymt3_ctx::Resampler** out) {
+    const long long g = gcd_ll(sr_in, c->cfg.sample_rate);
+    const int up = (int)(c->cfg.sample_rate / g), down = (int)(sr_in / g);
+    auto it = c->resamplers.find({up, down});
+    if (it != c->resamplers.end()) { *out = &it->second; return YMT3_OK; }
+    const int max_rate = std::max(up, down);
+    if (max_rate > 16384) FAIL(YMT3_ERR_UNSUPPORTED, "resampling ratio %d/%d needs a %d-tap filter; unsupported", up, down, 20 * max_rate + 1);
+    ymt3_ctx::Resampler rs;
+    rs.up = up; rs.down = down;
+    std::vector<double> hp;
+    if (up == 1 && down == 1) {
+        hp.assign(1, 1.0);
+        rs.r = 0;
+    } else {
+        const int half_len = 10 * max_rate, n = 2 * half_len + 1;
+        const int n_pre_pad = down - half_len % down;
+        rs.r = (half_len + n_pre_pad) / down;
+        hp.assign((size_t)n_pre_pad + n, 0.0);
+        const double fc = 1.0 / max_rate, i0b = bessel_i0(5.0), pi = 3.14159265358979323846;
+        double sum = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double m = (double)(i - half_len), xx = pi * fc * m;
+            const double sinc = m == 0.0 ? 1.0 : std::sin(xx) / xx;
+            const double rel = m / half_len;
+            const double w = bessel_i0(5.0 * std::sqrt(std::max(0.0, 1.0 - rel * rel))) / i0b;
+            hp[(size_t)n_pre_pad + i] = fc * sinc * w;
+            sum += hp[(size_t)n_pre_pad + i];
+        }
+        for (int i = 0; i < n; ++i) hp[(size_t)n_pre_pad + i] *= (double)up / sum;
+    }
+    rs.J = (int)((hp.size() + up - 1) / up);
+    rs.Jp = (rs.J + 3) / 4 * 4;
+    rs.window = (int)((255LL * down) / up) + rs.J + 2;
+    if ((size_t)rs.window * sizeof(float) > 64 * 1024) FAIL(YMT3_ERR_UNSUPPORTED, "resampling ratio %d/%d needs a %d-sample LDS window; unsupported", up, down, rs.window);
+    std::vector<float> P((size_t)up * rs.Jp, 0.f);
+    for (size_t i = 0; i < hp.size(); ++i) P[(i % up) * rs.Jp + i / up] = (float)hp[i];
+    void* dev = nullptr;
+    int rc = dev_alloc(c, &dev, P.size() * sizeof(float));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dev, P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice));
+    rs.taps = static_cast<float*>(dev);
+    *out = &(c->resamplers[{up, down}] = rs);
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_ingest_plan(ymt3_handle h, int64_t n_frames, int sample_rate_in, int64_t* n_samples_out, int* n_segments) {
+    if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (n_frames < 0 || sample_rate_in <= 0) FAIL(YMT3_ERR_ARG, "n_frames=%lld sample_rate_in=%d", (long long)n_frames, sample_rate_in);
+    const long long g = gcd_ll(sample_rate_in, h->cfg.sample_rate);
+    const long long up = h->cfg.sample_rate / g, down = sample_rate_in / g;
+    const long long n_out = (n_frames * up + down - 1) / down;
+    const long long S = h->cfg.segment_samples;
+    const long long n_seg = std::max(1LL, (n_out + S - 1) / S);
+    if (n_seg > 0x7fffffffLL) FAIL(YMT3_ERR_ARG, "too many segments");
+    if (n_samples_out) *n_samples_out = n_out;
+    if (n_segments) *n_segments = (int)n_seg;
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_ingest(ymt3_handle h, const void* pcm_dev, int pcm_format, int64_t n_frames, int n_channels,
+                           int sample_rate_in, float* segments_dev, int n_segments, void* stream) {
+    if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (pcm_format != YMT3_PCM_S16 && pcm_format != YMT3_PCM_F32) FAIL(YMT3_ERR_ARG, "pcm_format=%d", pcm_format);
+    if (n_frames < 0 || n_channels < 1 || n_channels > 64 || sample_rate_in <= 0 || n_segments < 1)
+        FAIL(YMT3_ERR_ARG, "n_frames=%lld n_channels=%d sample_rate_in=%d n_segments=%d", (long long)n_frames, n_channels, sample_rate_in, n_segments);
+    if (!segments_dev || (n_frames > 0 && !pcm_dev)) FAIL(YMT3_ERR_ARG, "null buffer");
+    int64_t n_out = 0;
+    int need = 0;
+    int rc = ymt3_ingest_plan(h, n_frames, sample_rate_in, &n_out, &need);
+    if (rc) return rc;
+    if (n_segments < need) FAIL(YMT3_ERR_ARG, "n_segments=%d but %lld resampled samples need %d", n_segments, (long long)n_out, need);
+    HIP_TRY(hipSetDevice(h->device));
+    const ymt3_ctx::Resampler* rs = nullptr;
+    rc = get_resampler(h, sample_rate_in, &rs);
+    if (rc) return rc;
+    IngestArgs a{};
+    a.pcm = pcm_dev; a.taps = rs->taps; a.out = segments_dev;
+    a.n_in = n_frames; a.n_out = n_out; a.n_total = (long long)n_segments * h->cfg.segment_samples; a.r = rs->r;
+    a.up = rs->up; a.down = rs->down; a.J = rs->J; a.Jp = rs->Jp; a.n_channels = n_channels; a.s16 = pcm_format == YMT3_PCM_S16; a.window = rs->window;
+    LAUNCH(launch_ingest(a, (hipStream_t)stream));
+    HIP_TRY(hipGetLastError());
     return YMT3_OK;
 }
 

@@ -73,6 +73,29 @@ class YourMT3:
         _lib.check(self._lib.ymt3_set_early_stop(self._handle, int(interval)))
 
     # ------------------------------------------------------------------ stages (C ABI, 1:1)
+    def ingest(self, pcm: torch.Tensor, sample_rate: int) -> torch.Tensor:
+        """(n_frames, n_channels) or (n_frames,) int16 / float32 PCM at `sample_rate` -> (n_seg, 1, S) float32 mono
+        segments at cfg.sample_rate on the device (mix, resample, slice and zero-pad in one kernel)."""
+        if pcm.dim() == 1:
+            pcm = pcm[:, None]
+        if pcm.dim() != 2:
+            raise ValueError("pcm must be (n_frames, n_channels)")
+        if pcm.dtype == torch.int16:
+            fmt = 0
+        elif pcm.dtype == torch.float32:
+            fmt = 1
+        else:
+            raise ValueError("pcm must be int16 or float32")
+        pcm = pcm.to(self.device).contiguous()
+        n_frames, n_ch = int(pcm.shape[0]), int(pcm.shape[1])
+        n_out, n_seg = ctypes.c_int64(0), ctypes.c_int(0)
+        _lib.check(self._lib.ymt3_ingest_plan(self._handle, n_frames, int(sample_rate), ctypes.byref(n_out), ctypes.byref(n_seg)))
+        segs = torch.empty(n_seg.value, 1, self.cfg.segment_samples, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.ymt3_ingest(self._handle, _ptr(pcm) if n_frames else None, fmt, n_frames, n_ch, int(sample_rate),
+                                         _ptr(segs), n_seg.value, self._stream()))
+        self.last_ingest_samples = int(n_out.value)
+        return segs
+
     def logmel(self, audio: torch.Tensor) -> torch.Tensor:
         a = self._audio2d(audio)
         B = a.shape[0]

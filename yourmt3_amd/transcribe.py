@@ -9,7 +9,7 @@ from typing import Optional, Union
 import numpy as np
 import torch
 
-from .audio import load_wav, resample, slice_padded_array
+from .audio import load_wav_pcm
 from .midi import write_midi
 from .task_manager import TaskManager
 
@@ -24,18 +24,19 @@ def transcribe(model, audio_info: Union[str, dict, np.ndarray], task_manager: Op
     if isinstance(audio_info, dict):
         path = audio_info["filepath"]
         name = audio_info.get("track_name") or os.path.splitext(os.path.basename(path))[0]
-        x, sr = load_wav(path)
+        x, sr = load_wav_pcm(path)
     elif isinstance(audio_info, str):
         path, name = audio_info, os.path.splitext(os.path.basename(audio_info))[0]
-        x, sr = load_wav(path)
+        x, sr = load_wav_pcm(path)
     else:
         x, sr, name = np.asarray(audio_info, dtype=np.float32), cfg.sample_rate, "audio"
-    x = resample(x, sr, cfg.sample_rate)
-    segments = slice_padded_array(x, cfg.segment_samples)
+    # mono mix, resample to the model rate, slice and zero-pad on the device (C ABI: ymt3_ingest)
+    segments = model.ingest(torch.from_numpy(np.ascontiguousarray(x)), sr)
+    n_samples = model.last_ingest_samples
     start_secs = [i * cfg.segment_samples / cfg.sample_rate for i in range(segments.shape[0])]
     L = max_token_length or task_manager.max_note_token_length
-    batches = model.inference_file(bsz, torch.from_numpy(segments), max_token_length=min(L, cfg.max_decode_len))
-    notes = task_manager.tokens_to_notes(batches, start_secs, end_sec=len(x) / cfg.sample_rate)
+    batches = model.inference_file(bsz, segments, max_token_length=min(L, cfg.max_decode_len))
+    notes = task_manager.tokens_to_notes(batches, start_secs, end_sec=n_samples / cfg.sample_rate)
     os.makedirs(output_dir, exist_ok=True)
     midi_path = write_midi(notes, os.path.join(output_dir, name + ".mid"))
     return (midi_path, notes) if return_notes else midi_path
