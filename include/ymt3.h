@@ -100,6 +100,16 @@ int ymt3_set_early_stop(ymt3_handle h, int interval);
 int ymt3_transcribe_segments(ymt3_handle h, const float* audio_dev, int B, int n_steps,
                              int32_t* tokens_dev, void* stream);
 
+/* Continuous batching: transcribe a queue of `n_segments` segments, audio (n_segments,
+ * segment_samples) f32 -> ids (n_segments, n_channels, n_steps) int32, through `slots` decoder slots (<= 0 or
+ * > max_batch: max_batch).  Every row decodes at its own position; every `interval` steps (0: 8) the host reads the
+ * per-row stop flags, retires segments whose rows have all emitted EOS (or n_steps tokens; the tail is PAD, exactly
+ * what the lock-step calls produce) and encodes the next pending segments into the freed slots.  The ids are bit-identical
+ * to ymt3_transcribe_segments on the same segments.  Synchronises the stream (once per interval) and returns when the
+ * queue is done. */
+int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int n_segments, int n_steps, int32_t* tokens_dev,
+                           int slots, int interval, void* stream);
+
 /* Measurement hook (bench.py `roofline`): decode eagerly (no graph) and bracket every kernel launch of
  * every `stride`-th step (positions stride/2, 3*stride/2, ...) with HIP events on `stream`; synchronises the stream before returning.
  * Classes: 0 qkv+cache GEMM, 1 self-attention, 2 self O-proj, 3 cross Q GEMM, 4 cross-attention,

@@ -536,3 +536,44 @@ def test_ingest_edges_and_errors(small):
     # exact multiple of the segment length: no extra padded segment
     seg = small.ingest(torch.ones(2 * SMALL.segment_samples, dtype=torch.float32), 16000)
     assert seg.shape[0] == 2 and float((seg - 1).abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- continuous batching (8f rank 4)
+def _pick_eos(tokens):
+    """a token id whose first occurrence falls at different steps for different rows (so rows stop at different lengths)"""
+    flat = tokens.reshape(-1, tokens.shape[-1])
+    best, best_score = None, -1
+    for cand in np.unique(flat):
+        first = [int(np.argmax(row == cand)) if (row == cand).any() else -1 for row in flat]
+        score = len(set(first))
+        if score > best_score:
+            best, best_score = int(cand), score
+    return best, best_score
+
+
+@pytest.mark.parametrize("base", [SMALL, MC3], ids=["single-channel", "3-channel"])
+def test_continuous_batching_equals_lockstep_batches(base):
+    import dataclasses
+    n_seg = 9
+    audio = O.synthetic_audio(n_seg, base)
+    free = _model(dataclasses.replace(base, eos_id=-1))
+    toks = np.concatenate(free.inference_file(4, audio), 0)
+    free.close()
+    eos, spread = _pick_eos(toks)
+    assert spread >= 3, "the synthetic decode offers no token that stops rows at >= 3 different lengths"
+    cfg = dataclasses.replace(base, eos_id=eos)
+    m = _model(cfg)
+    ref = np.concatenate(m.inference_file(4, audio), 0)                   # lock-step batches of 4, 4, 1 with EOS -> PAD fill
+    L = ref.shape[-1]
+    stops = [int(np.argmax(r == eos)) if (r == eos).any() else L for r in ref.reshape(-1, L)]
+    assert len(set(stops)) >= 3 and (ref.reshape(-1, L)[0, stops[0] + 1:] == cfg.pad_id).all()
+    for slots, interval in [(3, 4), (1, 1), (4, 7), (0, 0)]:
+        got = m.inference_stream(audio, slots=slots, interval=interval).cpu().numpy()
+        assert got.shape == ref.shape and np.array_equal(got, ref), (slots, interval)
+    assert np.array_equal(m.inference_stream(audio[:2], slots=4).cpu().numpy(), ref[:2])      # fewer segments than slots
+    assert np.array_equal(m.inference_stream(audio, max_token_length=16, slots=2).cpu().numpy(),
+                          np.concatenate(m.inference_file(4, audio, max_token_length=16), 0))  # length cap below max_decode_len
+    assert m.inference_stream(audio[:0]).shape == (0, cfg.n_channels, cfg.max_decode_len)
+    # the lock-step path is untouched by a stream call in between
+    assert np.array_equal(np.concatenate(m.inference_file(4, audio), 0), ref)
+    m.close()

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             if (n < inner) {
                 *reinterpret_cast<uint32_t*>(a.out_bf16 + (size_t)m * inner + n) = pk;
             } else {
-                const int step = a.shared->step;
+                const int step = a.row_pos ? a.row_pos[m] : a.shared->step;
                 const int nn = n - inner, kv = nn / inner, hh = (nn % inner) >> 6, dd = nn & 63;
                 bf16_t* cache = kv ? a.vcache : a.kcache;
                 *reinterpret_cast<uint32_t*>(cache + (((size_t)m * a.H + hh) * a.L + step) * DKV + dd) = pk;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane & 7, kg = lane >> 3;
     const int r = a.row0 + blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const int n_keys = SELF ? a.shared->step + 1 : a.n_keys_const;
+    const int n_keys = SELF ? (a.row_pos ? a.row_pos[r] : a.shared->step) + 1 : a.n_keys_const;
     const int kv_row = r / a.rows_per_kv;
     const size_t slab = ((size_t)kv_row * a.H + h) * a.slab_keys * DKV;
     const bf16_t* kb = a.k + slab + sub * 8;
@@ -459,7 +459,22 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     }
     if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && a.row_pos) {
+        // slot mode: this row's own position; a stopped row writes nothing and stays where it is (its slot is refilled
+        // by the host), a live one stops after EOS or its n_steps-th token
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        int feed = a.pad_id;
+        if (!a.finished[r]) {
+            const int p = a.row_pos[r];
+            sh->tokens_out[a.row_out[r] + p] = bi;
+            if ((a.eos_id >= 0 && bi == a.eos_id) || p + 1 >= n_steps) a.finished[r] = 1;
+            else a.row_pos[r] = p + 1;
+            feed = bi;
+        }
+        s_feed = feed;
+    } else if (tid == 0) {
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     const bf16_t* e = a.embed + (size_t)feed * a.d;
     const bf16_t* c = a.chan_embed ? a.chan_embed + (size_t)(r % a.n_channels) * a.d : nullptr;
     embed_row(a, r, e, c, sv);
-    if (sh->logits_out) {
+    if (sh->logits_out && !a.row_pos) {
         float* dst = sh->logits_out + ((size_t)r * n_steps + col) * a.V;
         for (int i = tid; i < a.V; i += 256) dst[i] = row[i];
     }
@@ -517,6 +532,25 @@ __global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_ch
         sh->forced = forced;
         sh->logits_out = logits_out;
     }
+}
+
+__global__ __launch_bounds__(256) void slot_start_kernel(ArgmaxArgs a, int row0, long long first_out, int n_steps, long long* row_out) {
+    const int r = row0 + blockIdx.x, tid = threadIdx.x;
+    const bf16_t* e = a.embed + (size_t)a.pad_id * a.d;
+    const bf16_t* c = a.chan_embed ? a.chan_embed + (size_t)(r % a.n_channels) * a.d : nullptr;
+    __shared__ float sv[4];
+    embed_row(a, r, e, c, sv);
+    if (tid == 0) {
+        a.finished[r] = 0;
+        a.row_pos[r] = 0;
+        row_out[r] = first_out + (long long)blockIdx.x * n_steps;
+    }
+}
+
+__global__ void slot_retire_kernel(ArgmaxArgs a, int row0, int n_steps, int32_t* tokens_out) {
+    const int r = row0 + blockIdx.x;
+    int32_t* row = tokens_out + a.row_out[r];
+    for (int i = a.row_pos[r] + 1 + threadIdx.x; i < n_steps; i += blockDim.x) row[i] = a.pad_id;
 }
 
 __global__ void pad_tail_kernel(int32_t* tokens_out, int row0, int n_steps, int from, int pad_id) {
@@ -598,6 +632,18 @@ int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int step0
                        float* logits_out, hipStream_t stream) {
     if (a.R <= 0) return 0;
     decode_init_kernel<<<a.R, 256, 0, stream>>>(a, n_chains, n_steps, step0, tokens_out, forced, logits_out);
+    return 0;
+}
+
+int launch_slot_start(const ArgmaxArgs& a, int row0, long long first_out, int n_steps, long long* row_out, hipStream_t stream) {
+    if (!a.row_pos || !row_out || a.n_channels <= 0) return -1;
+    slot_start_kernel<<<a.n_channels, 256, 0, stream>>>(a, row0, first_out, n_steps, row_out);
+    return 0;
+}
+
+int launch_slot_retire(const ArgmaxArgs& a, int row0, int n_rows, int n_steps, int32_t* tokens_out, hipStream_t stream) {
+    if (!a.row_pos || !a.row_out || n_rows <= 0) return -1;
+    slot_retire_kernel<<<n_rows, 256, 0, stream>>>(a, row0, n_steps, tokens_out);
     return 0;
 }
 

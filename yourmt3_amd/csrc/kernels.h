@@ -88,6 +88,7 @@ struct DecGemmArgs {
     bf16_t* vcache;
     int H, L;                   // cache geometry
     const DecodeShared* shared; // MODE_QKV_CACHE reads shared->step
+    const int* row_pos;         // slot mode (ymt3_transcribe_stream): per-row positions replace shared->step; else null
     float* ssq;                 // [SSQ_TILES][ssq_stride] per-row partial sums of h^2 (read by NORM, written by RESID)
     int ssq_stride;
 };
@@ -102,6 +103,7 @@ struct DecAttnArgs {
     bf16_t* out;                // [R][H*64]
     const float* bias;          // [H][L] by distance (self) or null (cross)
     const DecodeShared* shared; // self: n_keys = shared->step + 1
+    const int* row_pos;         // slot mode: n_keys = row_pos[r] + 1; else null
     int n_keys_const;           // cross: fixed key count
     int slab_keys;              // keys allocated per (row, head) slab (L for self, T for cross)
     int rows_per_kv;            // 1 for self; n_channels for cross (row r reads segment r / n_channels)
@@ -140,10 +142,19 @@ struct ArgmaxArgs {
     float* ssq;                 // [SSQ_TILES][ssq_stride]
     int ssq_stride;
     int row0, R, V, d, n_channels, eos_id, pad_id;
+    // slot mode (ymt3_transcribe_stream; both null otherwise): every row decodes at its own position row_pos[r] and
+    // writes token p to tokens_out[row_out[r] + p]; a row stops (finished = 1, position frozen) after EOS or n_steps tokens
+    int* row_pos;               // [R]
+    const long long* row_out;   // [R]
 };
 int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream);
 // tokens_out[r][from .. n_steps) = pad for rows [row0, row0 + R): the tail of a decode that stopped early
 int launch_pad_tail(int32_t* tokens_out, int row0, int R, int n_steps, int from, int pad_id, hipStream_t stream);
+// slot mode: (re)start rows [row0, row0 + n_channels) on a new segment: h = embed[pad] (+ channel), position 0,
+// finished = 0, row_out = first_out + channel * n_steps
+int launch_slot_start(const ArgmaxArgs& a, int row0, long long first_out, int n_steps, long long* row_out, hipStream_t stream);
+// slot mode: PAD the unwritten tail [row_pos + 1, n_steps) of rows [row0, row0 + n_rows)
+int launch_slot_retire(const ArgmaxArgs& a, int row0, int n_rows, int n_steps, int32_t* tokens_out, hipStream_t stream);
 // all rows: h[r] = embed[pad] (+ chan_embed), finished = 0; a.shared[0..n_chains) reset
 int launch_decode_init(const ArgmaxArgs& a, int n_chains, int n_steps, int step0, int32_t* tokens_out, const int32_t* forced,
                        float* logits_out, hipStream_t stream);

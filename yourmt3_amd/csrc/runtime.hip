@@ -75,6 +75,11 @@ struct ymt3_ctx {
     float* ssq = nullptr;               // [SSQ_TILES][maxR]
     MoeArgs moe{};                      // scratch pointers of the MoE FFN (dec_ffn == YMT3_FFN_MOE)
     int* finished = nullptr;
+    // slot mode (ymt3_transcribe_stream): per-row positions and output offsets; launch_step wires them in while set
+    int* row_pos = nullptr;             // [maxR]
+    long long* row_out = nullptr;       // [maxR]
+    int* host_rows = nullptr;           // pinned [maxR]: copy of `finished` for the host's retire/admit decisions
+    bool slot_mode = false;
     DecodeShared* shared = nullptr;     // [MAX_CHAINS] per-chain loop state
     hipStream_t cap_stream = nullptr;
     // Decode rows are independent, so a batch CAN be cut into `n_chains` contiguous row ranges whose
@@ -191,6 +196,7 @@ extern "C" void ymt3_destroy(ymt3_handle h) {
     }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->host_flag) (void)hipHostFree(h->host_flag);
+    if (h->host_rows) (void)hipHostFree(h->host_rows);
     for (int i = 0; i < 8; ++i) {
         if (h->chain_stream[i]) (void)hipStreamDestroy(h->chain_stream[i]);
         if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
@@ -278,6 +284,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->dff, R * k.d_ff * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->logits, R * k.vocab * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->finished, R * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->row_pos, R * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->row_out, R * 8)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->ssq, (size_t)SSQ_TILES * R * 4)) return YMT3_ERR_HIP;
     if (k.dec_ffn == YMT3_FFN_MOE) {
         MoeArgs& m = c->moe;
@@ -471,6 +479,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         const LayerW& W = LW[l];
         DecGemmArgs a{};
         a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
+        a.row_pos = h->slot_mode ? h->row_pos : nullptr;
         // self-attention block
         a.x_f32 = h->h_dec; a.gain = W.ln1; a.W = W.wqkv; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
         a.kcache = h->kcache + l * layer_cache; a.vcache = h->vcache + l * layer_cache;
@@ -478,6 +487,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         DecAttnArgs t{};
         t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
         t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
+        t.row_pos = a.row_pos;
         PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
         a.a_bf16 = h->dattn; a.W = W.wo; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
         PLAUNCH(PC_SELF_O, launch_dec_gemm(DG_RESID, a, s));
@@ -528,6 +538,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     g.R = R; g.V = k.vocab; g.d = d; g.n_channels = k.n_channels; g.eos_id = k.eos_id; g.pad_id = k.pad_id;
     GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&g.embed), (size_t)k.vocab * d);
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&g.chan_embed), (size_t)k.n_channels * d);
+    if (h->slot_mode) { g.row_pos = h->row_pos; g.row_out = h->row_out; }
     PLAUNCH(PC_ARGMAX, launch_argmax_embed(g, s));
     return YMT3_OK;
 }
@@ -649,6 +660,110 @@ extern "C" int ymt3_transcribe_segments(ymt3_handle h, const float* audio_dev, i
     rc = encode_impl(h, h->mel, B, h->enc_out, s);
     if (rc) return rc;
     return decode_impl(h, h->enc_out, B, n_steps, tokens_dev, nullptr, nullptr, s);
+}
+
+// continuous batching.  `slots` decoder slots are kept busy from a queue of segments: each row
+// decodes at its own position (slot mode of the step kernels), the host looks at the per-row `finished` flags every
+// `interval` steps, pads and retires segments whose rows have all stopped, and encodes the next pending segments straight
+// into the freed slots (log-mel + encoder batched over the admissions, cross-K/V written into each slot's slabs).  Rows are
+// independent in every kernel, so the ids equal those of lock-step batches bit for bit.
+extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int n_segments, int n_steps, int32_t* tokens_dev,
+                                      int slots, int interval, void* stream) {
+    int rc = check_call(h, 0);
+    if (rc) return rc;
+    if (n_segments < 0) FAIL(YMT3_ERR_ARG, "n_segments=%d", n_segments);
+    if (n_segments == 0) return YMT3_OK;
+    if (!audio_dev || !tokens_dev) FAIL(YMT3_ERR_ARG, "null buffer");
+    const ymt3_config& k = h->cfg;
+    if (n_steps <= 0 || n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len);
+    if (interval < 0) FAIL(YMT3_ERR_ARG, "interval=%d", interval);
+    if (interval == 0) interval = 8;
+    if (slots <= 0 || slots > h->maxB) slots = h->maxB;
+    if (slots > n_segments) slots = n_segments;
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->host_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_rows), (size_t)h->maxR * sizeof(int), hipHostMallocDefault));
+    const int K = k.n_channels, R = slots * K, d = k.d_model, T = h->T, H = k.n_heads;
+    const size_t S = (size_t)k.segment_samples;
+
+    ArgmaxArgs a{};
+    a.h = h->h_dec; a.shared = h->shared; a.finished = h->finished; a.ssq = h->ssq; a.ssq_stride = h->maxR;
+    a.R = R; a.V = k.vocab; a.d = d; a.n_channels = K; a.eos_id = k.eos_id; a.pad_id = k.pad_id;
+    a.row_pos = h->row_pos; a.row_out = h->row_out;
+    GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&a.embed), (size_t)k.vocab * d);
+    if (K > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&a.chan_embed), (size_t)K * d);
+
+    struct ModeGuard { ymt3_ctx* c; ~ModeGuard() { c->slot_mode = false; } } guard{h};
+    h->slot_mode = true;
+    // loop state: every row starts stopped; admissions start them
+    LAUNCH(launch_decode_init(a, 1, n_steps, 0, tokens_dev, nullptr, nullptr, s));
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->finished), 1, (size_t)R, s));
+    HIP_TRY(hipMemsetAsync(h->row_pos, 0, (size_t)R * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(h->row_out, 0, (size_t)R * sizeof(long long), s));
+
+    hipGraphExec_t exec = nullptr;
+    if (h->use_graph) {
+        StepGraph& sg = h->step_graphs[((long)slots * 16 + 15) * 16];      // 15: slot-mode graph of `slots` segments
+        if (!sg.exec) {
+            HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            int rcs = launch_step(h, slots, 0, R, h->shared, h->cap_stream);
+            hipError_t e = hipStreamEndCapture(h->cap_stream, &sg.graph);
+            if (rcs) return rcs;
+            if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIP_TRY(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+        }
+        exec = sg.exec;
+    }
+
+    std::vector<int> slot_seg((size_t)slots, -1), free_slots;
+    auto admit = [&](int first_seg, int nb) -> int {
+        LAUNCH(launch_logmel(h->fe, audio_dev + (size_t)first_seg * S, h->mel, nb, s));
+        int rce = encode_impl(h, h->mel, nb, h->enc_out, s);
+        if (rce) return rce;
+        for (int i = 0; i < nb; ++i) {
+            const int slot = free_slots[(size_t)i];
+            GemmArgs g{h->enc_out + (size_t)i * T * d, h->wkv_all, h->ckv + (size_t)slot * H * T * 64, nullptr,
+                       T, k.n_dec_layers * 2 * h->inner, d, d, d, 0, T, H, slots};
+            LAUNCH(launch_gemm(EPI_KV_HEADMAJOR, g, s));
+            LAUNCH(launch_slot_start(a, slot * K, (long long)(first_seg + i) * K * n_steps, n_steps, h->row_out, s));
+            slot_seg[(size_t)slot] = first_seg + i;
+        }
+        return YMT3_OK;
+    };
+    for (int i = 0; i < slots; ++i) free_slots.push_back(i);
+    rc = admit(0, slots);
+    if (rc) return rc;
+    int next = slots, live = slots;
+    // every live segment stops within n_steps steps, so the loop is bounded; the guard only catches a logic error
+    const long max_rounds = ((long)n_segments / slots + 2) * ((n_steps + interval - 1) / interval + 1);
+    for (long round = 0; live > 0; ++round) {
+        if (round > max_rounds) FAIL(YMT3_ERR_HIP, "slot scheduler made no progress (%d live, %d admitted of %d)", live, next, n_segments);
+        for (int i = 0; i < interval; ++i) {
+            if (exec) HIP_TRY(hipGraphLaunch(exec, s));
+            else { int rcs = launch_step(h, slots, 0, R, h->shared, s); if (rcs) return rcs; }
+        }
+        HIP_TRY(hipMemcpyAsync(h->host_rows, h->finished, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        free_slots.clear();
+        for (int slot = 0; slot < slots; ++slot) {
+            if (slot_seg[(size_t)slot] < 0) continue;
+            bool all = true;
+            for (int c = 0; c < K; ++c) all = all && h->host_rows[slot * K + c] != 0;
+            if (!all) continue;
+            LAUNCH(launch_slot_retire(a, slot * K, K, n_steps, tokens_dev, s));
+            slot_seg[(size_t)slot] = -1;
+            --live;
+            free_slots.push_back(slot);
+        }
+        const int nb = std::min((int)free_slots.size(), n_segments - next);
+        if (nb > 0) {
+            rc = admit(next, nb);
+            if (rc) return rc;
+            next += nb;
+            live += nb;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return YMT3_OK;
 }
 
 extern "C" int ymt3_test_gemm(ymt3_handle h, const void* a_dev, const void* w_dev, float* c_dev, int M, int N, int K, void* stream) {

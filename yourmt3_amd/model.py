@@ -134,6 +134,21 @@ class YourMT3:
         _lib.check(self._lib.ymt3_transcribe_segments(self._handle, _ptr(a), B, L, _ptr(tokens), self._stream()))
         return tokens
 
+    def inference_stream(self, audio_segments: torch.Tensor, max_token_length: Optional[int] = None, slots: int = 0,
+                         interval: int = 8) -> torch.Tensor:
+        """(N, 1, S) or (N, S) audio, any N -> (N, K, L) int32 ids with continuous batching: `slots` decoder slots are
+        refilled from the queue as segments emit EOS (needs eos_id >= 0 to gain anything).  Ids equal inference()'s."""
+        a = audio_segments[:, 0, :] if audio_segments.dim() == 3 else audio_segments
+        if a.shape[-1] != self.cfg.segment_samples:
+            raise ValueError(f"segments must have {self.cfg.segment_samples} samples, got {a.shape[-1]}")
+        a = a.to(self.device, torch.float32).contiguous()
+        N = a.shape[0]
+        L = int(max_token_length or self.cfg.max_decode_len)
+        tokens = torch.empty(N, self.cfg.n_channels, L, device=self.device, dtype=torch.int32)
+        _lib.check(self._lib.ymt3_transcribe_stream(self._handle, _ptr(a) if N else None, N, L, _ptr(tokens) if N else None,
+                                                    int(slots), int(interval), self._stream()))
+        return tokens
+
     def inference_file(self, bsz: int, audio_segments: torch.Tensor, max_token_length: Optional[int] = None) -> List[np.ndarray]:
         """Split (N, 1, S) segments into batches of `bsz`; one (b, K, L) int array per batch."""
         bsz = min(int(bsz), self.max_batch)
