@@ -291,6 +291,8 @@ def test_transcribe_writes_a_midi_file(small, tmp_path):
     data = open(path, "rb").read()
     assert data[:4] == b"MThd"
     assert len(read_midi_notes(data)) == len(notes)       # random weights: any notes, but a well-formed file
+    path2, notes2 = transcribe(small, audio, bsz=2, output_dir=str(tmp_path / "c"), max_token_length=32, return_notes=True, continuous=True)
+    assert open(path2, "rb").read() == data               # continuous batching: same ids, same file
 
 
 def _moe_case(cfg, n, tol_max, tol_mean, tau, gap=0.005):

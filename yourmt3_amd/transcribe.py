@@ -15,7 +15,10 @@ from .task_manager import TaskManager
 
 
 def transcribe(model, audio_info: Union[str, dict, np.ndarray], task_manager: Optional[TaskManager] = None, bsz: int = 8,
-               output_dir: str = ".", max_token_length: Optional[int] = None, return_notes: bool = False):
+               output_dir: str = ".", max_token_length: Optional[int] = None, return_notes: bool = False,
+               continuous: bool = False):
+    """`continuous=True` decodes the file's segments through `bsz` slots with continuous batching
+    (YourMT3.inference_stream: segments leave at EOS and the next ones enter) instead of fixed batches; same ids."""
     cfg = model.cfg
     if task_manager is None:
         task_manager = TaskManager("mc13_full_plus_256" if cfg.n_channels == 13 else "mt3_full_plus")
@@ -35,7 +38,10 @@ def transcribe(model, audio_info: Union[str, dict, np.ndarray], task_manager: Op
     n_samples = model.last_ingest_samples
     start_secs = [i * cfg.segment_samples / cfg.sample_rate for i in range(segments.shape[0])]
     L = max_token_length or task_manager.max_note_token_length
-    batches = model.inference_file(bsz, segments, max_token_length=min(L, cfg.max_decode_len))
+    if continuous:
+        batches = [model.inference_stream(segments, max_token_length=min(L, cfg.max_decode_len), slots=bsz).cpu().numpy()]
+    else:
+        batches = model.inference_file(bsz, segments, max_token_length=min(L, cfg.max_decode_len))
     notes = task_manager.tokens_to_notes(batches, start_secs, end_sec=n_samples / cfg.sample_rate)
     os.makedirs(output_dir, exist_ok=True)
     midi_path = write_midi(notes, os.path.join(output_dir, name + ".mid"))
