@@ -103,6 +103,25 @@ def test_gemm_matches_fp32_matmul(small, M, N, K):
     assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()) * (K ** 0.5)
 
 
+@pytest.mark.parametrize("M,N,K", [(4224, 1024, 512), (8192, 512, 64), (8192, 512, 128), (4100, 1024, 192), (4096, 1024, 2048), (16384, 2048, 512)])
+def test_pipelined_large_m_gemm(small, M, N, K):
+    """The 256 x 128 three-stage kernel (taken when its tiles fill >= half the chip): 1, 2, 3, 8 and 32 K-steps, ragged M,
+    and a permutation probe (row i of A selects column i % K of W) that exposes any stage / fragment / swizzle mix-up exactly."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = torch.randn(N, K, generator=g).bfloat16()
+    ref = A.float() @ W.float().T
+    got = small.test_gemm(A.cuda(), W.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()) * (K ** 0.5)
+    P = torch.zeros(M, K).bfloat16()
+    P[torch.arange(M), (torch.arange(M) * 7) % K] = 1
+    Wp = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :]).float().remainder(251).bfloat16()
+    got = small.test_gemm(P.cuda(), Wp.cuda()).cpu()
+    assert torch.equal(got, Wp.float()[:, (torch.arange(M) * 7) % K].T.contiguous())
+    for _ in range(3):                                       # repeated launches: a stage read before its DMA landed would differ
+        assert torch.equal(small.test_gemm(P.cuda(), Wp.cuda()).cpu(), got)
+
+
 # ----------------------------------------------------------------------------- encoder
 @pytest.mark.parametrize("which", ["small", "full"])
 def test_encoder_matches_oracle(which, request):
@@ -114,6 +133,26 @@ def test_encoder_matches_oracle(which, request):
     got = m.encode(mel.cuda()).float().cpu()
     d = (got - ref).abs()
     assert d.max().item() <= 0.0625 and d.mean().item() <= 4e-3
+
+
+def test_encoder_large_batch_takes_the_pipelined_gemm():
+    """16 segments x 256 frames = 4096 rows: the QKV / FFN-in / cross-KV projections run the persistent 256 x 128 kernel with
+    its LDS-turned bf16 epilogues (the 512-column projections stay on the 128 x 128 one).  Against the oracle, and bitwise
+    against the same segments encoded in batches of 2 (all on the 128 x 128 kernel: same K order, so identical sums)."""
+    m = _model(FULL, max_batch=16)
+    a = O.synthetic_audio(16, FULL, seed=5)
+    mel = O.logmel(a, FULL)
+    got = m.encode(mel.cuda())
+    ref = O.encoder_t5(O.input_projection(mel[:3], m.weights, True), m.weights, FULL, True)
+    err = (got[:3].float().cpu() - ref).abs()
+    assert err.max().item() <= 0.0625 and err.mean().item() <= 4e-3
+    for i in range(0, 16, 2):
+        assert torch.equal(m.encode(mel[i:i + 2].cuda()), got[i:i + 2])
+    # cross-K/V (head-major epilogue) + decode: batch of 16 == batches of 2, bit for bit
+    t16 = m.decode(got, 8)
+    for i in range(0, 16, 2):
+        assert torch.equal(m.decode(got[i:i + 2], 8), t16[i:i + 2])
+    m.close()
 
 
 # ----------------------------------------------------------------------------- decoder

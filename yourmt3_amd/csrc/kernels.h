@@ -43,6 +43,7 @@ struct GemmArgs {
     int T, H, n_seg;      // EPI_KV_HEADMAJOR only: frames per segment, heads, segments
 };
 int launch_gemm(int epilogue, const GemmArgs& a, hipStream_t stream);
+int init_gemm_kernels();
 
 // ---------------------------------------------------------------- norm / casts (norm.hip)
 // out bf16 [M][d] = R(x * rsqrt(mean(x^2) + eps) * gain)

@@ -229,7 +229,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     HIP_TRY(hipSetDevice(c->device));
     int rc = parse_blob(c, blob, nbytes);
     if (rc) return rc;
-    if (init_enc_attn_kernels() || init_decode_kernels() || init_moe_kernels() || init_mc_cross_kernels()) FAIL(YMT3_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
+    if (init_gemm_kernels() || init_enc_attn_kernels() || init_decode_kernels() || init_moe_kernels() || init_mc_cross_kernels()) FAIL(YMT3_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed");
 
     // front-end tables (built by yourmt3_amd/tables.py, carried in the blob)
     const int nfft = k.n_fft;
