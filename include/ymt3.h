@@ -120,6 +120,15 @@ int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int n_segments
 int ymt3_profile_decode(ymt3_handle h, const void* enc_dev, int B, int n_steps, int stride, int32_t* tokens_dev,
                         float* ms_by_class, int32_t* launches_by_class, void* stream);
 
+/* Measurement hook: when the handle was created with YMT3_STAMP=1 in the environment, every decode-step kernel records a
+ * 100 MHz wall-clock value per workgroup at entry and at the end of its last wave (last step executed wins).  This call
+ * synchronises the device and reduces them: for kernel i of the step (launch order; cls[i] = class as in
+ * ymt3_profile_decode, grid[i] = workgroups) stats[4i..4i+3] = earliest entry, latest entry, earliest exit, latest exit.
+ * Arrays hold 64 kernels. */
+int ymt3_debug_step_stamps(ymt3_handle h, int32_t* cls, int32_t* grid, uint64_t* stats, int* n_kernels);
+/* The raw (entry, exit) pairs of kernel `kernel` of the step, one per workgroup in blockIdx order (capacity in workgroups). */
+int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* stamps, int capacity_wgs);
+
 /* Measurement hook: later decode calls start at cache position `step0` instead of 0 (the cache below
  * it holds whatever earlier calls left, so the TOKENS are meaningless; the memory traffic of positions
  * step0.. is exactly that of a real decode).  Lets a profiler cover late positions in a short run:

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("YMT3_LIB", os.path.join(_HERE, "libymt3_hip.so"))
 SYMBOLS = [
     "ymt3_abi_version", "ymt3_last_error", "ymt3_create", "ymt3_destroy", "ymt3_device_bytes",
     "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm", "ymt3_profile_decode", "ymt3_set_profile_start", "ymt3_set_early_stop",
-    "ymt3_ingest_plan", "ymt3_ingest", "ymt3_transcribe_stream",
+    "ymt3_ingest_plan", "ymt3_ingest", "ymt3_transcribe_stream", "ymt3_debug_step_stamps", "ymt3_debug_kernel_stamps",
 ]
 
 _lib = None
@@ -65,6 +65,10 @@ def load() -> ctypes.CDLL:
     lib.ymt3_ingest.restype = i32
     lib.ymt3_transcribe_stream.argtypes = [vp, vp, i32, i32, vp, i32, i32, vp]
     lib.ymt3_transcribe_stream.restype = i32
+    lib.ymt3_debug_step_stamps.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int)]
+    lib.ymt3_debug_step_stamps.restype = i32
+    lib.ymt3_debug_kernel_stamps.argtypes = [vp, i32, vp, i32]
+    lib.ymt3_debug_kernel_stamps.restype = i32
     for n in ("ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm"):
         getattr(lib, n).restype = i32
     if lib.ymt3_abi_version() != 1:

@@ -33,6 +33,12 @@ namespace {
 constexpr int DKV = 64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Measurement only (YMT3_STAMP=1 at ymt3_create; the pointer is null otherwise): constant-rate wall clock (100 MHz) at the
+// first instruction of a workgroup and at the end of its last wave, read back by ymt3_debug_step_stamps to split a decode
+// step into launch gaps, dispatch ramps and kernel bodies.
+#define STAMP_IN(a) do { if ((a).stamp && threadIdx.x == 0) (a).stamp[2 * blockIdx.x] = wall_clock64(); } while (0)
+#define STAMP_OUT(a) do { if ((a).stamp && (threadIdx.x & 63) == 0) atomicMax((a).stamp + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64()); } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // 512 threads = 8 waves; one workgroup = a 16 rows x 16 columns output tile over the full K, each wave
 // owning K/8 of the reduction.  Small tiles keep every workgroup's operand traffic small (the per-CU load
@@ -59,6 +65,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     constexpr int PITCH = KW * 2 + 16;   // bytes per strip row (bf16 slice + 16 B pad against bank conflicts)
     constexpr int STRIP = 16 * PITCH;    // one operand strip (16 rows) of one wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    STAMP_IN(a);
     float* red = reinterpret_cast<float*>(smem);                    // [8][ROWS][16]
     float* sscale = red + 8 * ROWS * 16;                            // [ROWS]
     char* strips = smem + (8 * ROWS * 16 + ROWS) * 4;               // MT == 1: [8 waves][A strip | W strip]
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             *reinterpret_cast<uint32_t*>(a.out_bf16 + (size_t)m * a.N + n) = pk;
         }
     }
+    STAMP_OUT(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -231,6 +239,8 @@ __device__ __forceinline__ float sum8(float v) {
 // NW = waves per (row, head): 8 for up to ~2k workgroups (16 waves per CU keep > 12 MB in flight chip-wide); 2 when there
 // are many more (row, head) pairs than CUs (multi-channel / large batches), where 512-thread workgroups with a few keys
 // each only add dispatch rounds.
+// (Two rows per workgroup sharing the head's projection weights -- half the weight reads from L2 -- was measured and is
+// slower: 10.2 vs 8.7 us, eight waves per CU keep too little of the K/V stream in flight; profiles/r01_step_stamps.txt.)
 template <bool SELF, bool FUSEQ, int NW>
 __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {   // 4 waves / SIMD -> <= 128 VGPRs
     __shared__ float sm[NW], sl[NW], sacc[NW][DKV];
@@ -238,6 +248,7 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
     __shared__ __attribute__((aligned(16))) bf16_t qs[DKV];
     __shared__ float s_scale;
     const int tid = threadIdx.x, lane = tid & 63;
+    STAMP_IN(a);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane & 7, kg = lane >> 3;
     const int r = a.row0 + blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -342,16 +353,32 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
             load_block(ku, vu, ok, kw, nblk, full_tag);
             compute_block(ku, vu, ok, kw, nblk, full_tag);
         };
-        for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {     // wave-uniform trip count
+        for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {      // wave-uniform trip count
             // wave-uniform: blocks of 64 keys holding at least one valid key for this wave
             const int nblk = (n_keys - kw + 8 * NW - 1) / (8 * NW);
             if (n_keys - kw >= 8 * NW * U) block(kw, U, std::true_type{});
             else block(kw, nblk, std::false_type{});
         }
-    } else if (wave * 8 < n_keys) {
-        // first (for T <= 256: only) K/V block goes in flight now; its math waits for the projection below
-        const int kw = wave * 8, nblk = (n_keys - kw + 8 * NW - 1) / (8 * NW);
-        load_block(fku, fvu, fok, kw, nblk < U ? nblk : U, std::false_type{});
+    } else {
+        // every wave's projection operands are requested before ANY wave's K/V: the CU returns vector-memory data in request
+        // order, so weight lines (L2 hits) queued behind another wave's K/V lines (HBM) reached the projection only after
+        // most of the stream had arrived, and the projection ran exposed at the end (+2.7 us, profiles/r01_step_stamps.txt)
+        __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (FUSEQ) {
+        // first (for T <= 256: only) K/V block goes in flight now; its math waits for the projection below.  STRAIGHT-LINE
+        // code, keys beyond n_keys clamped to key 0 of the slab: behind a branch hipcc merges the two paths' load counts and
+        // waits for the projection operands with the count of the path that issued no K/V loads -- i.e. for (almost) the
+        // whole K/V stream, which put the projection after the stream instead of under it
+        const int k0 = wave * 8 + kg;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = k0 + 8 * NW * u;
+            fok[u] = key < n_keys;
+            const int kc = fok[u] ? key : 0;
+            fku[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV);
+            fvu[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV);
+        }
     }
     if constexpr (FUSEQ) {
         // norm scale (fixed-order tree over the 32 partials), normed row -> LDS as bf16-rounded floats
@@ -379,7 +406,7 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
         }
         __syncthreads();
         qp = *reinterpret_cast<const u32x4*>(qs + sub * 8);
-        // the block loaded above, then (T > 256 only) the remaining ones
+        // the block loaded above, then the remaining ones
         for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {
             const int nb = (n_keys - kw + 8 * NW - 1) / (8 * NW), nblk = nb < U ? nb : U;
             if (kw != wave * 8) load_block(fku, fvu, fok, kw, nblk, std::false_type{});
@@ -416,6 +443,7 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
         }
         a.out[((size_t)r * a.H + h) * DKV + tid] = f2bf(o / L);
     }
+    STAMP_OUT(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,6 +468,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     __shared__ int si[4];
     __shared__ int s_feed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    STAMP_IN(a);
     const int r = a.row0 + blockIdx.x;
     DecodeShared* sh = a.shared;
     const int t = sh->step, n_steps = sh->n_steps, col = t - sh->step0;   // col: index within this call
@@ -511,6 +540,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
             }
         }
     }
+    STAMP_OUT(a);
 }
 
 __global__ __launch_bounds__(256) void decode_init_kernel(ArgmaxArgs a, int n_chains, int n_steps, int step0, int32_t* tokens_out,

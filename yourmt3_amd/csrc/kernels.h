@@ -90,6 +90,7 @@ struct DecGemmArgs {
     int H, L;                   // cache geometry
     const DecodeShared* shared; // MODE_QKV_CACHE reads shared->step
     const int* row_pos;         // slot mode (ymt3_transcribe_stream): per-row positions replace shared->step; else null
+    unsigned long long* stamp;  // measurement (YMT3_STAMP=1): [grid][2] wall-clock entry / exit per workgroup; else null
     float* ssq;                 // [SSQ_TILES][ssq_stride] per-row partial sums of h^2 (read by NORM, written by RESID)
     int ssq_stride;
 };
@@ -105,6 +106,7 @@ struct DecAttnArgs {
     const float* bias;          // [H][L] by distance (self) or null (cross)
     const DecodeShared* shared; // self: n_keys = shared->step + 1
     const int* row_pos;         // slot mode: n_keys = row_pos[r] + 1; else null
+    unsigned long long* stamp;  // measurement: as DecGemmArgs::stamp
     int n_keys_const;           // cross: fixed key count
     int slab_keys;              // keys allocated per (row, head) slab (L for self, T for cross)
     int rows_per_kv;            // 1 for self; n_channels for cross (row r reads segment r / n_channels)
@@ -147,6 +149,7 @@ struct ArgmaxArgs {
     // writes token p to tokens_out[row_out[r] + p]; a row stops (finished = 1, position frozen) after EOS or n_steps tokens
     int* row_pos;               // [R]
     const long long* row_out;   // [R]
+    unsigned long long* stamp;  // measurement: as DecGemmArgs::stamp
 };
 int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream);
 // tokens_out[r][from .. n_steps) = pad for rows [row0, row0 + R): the tail of a decode that stopped early

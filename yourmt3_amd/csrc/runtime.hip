@@ -101,10 +101,22 @@ struct ymt3_ctx {
     int prof_step0 = 0;                     // ymt3_set_profile_start: decode positions begin here (measurement only)
     std::vector<hipEvent_t> prof_ev;        // pairs
     std::vector<int> prof_cls;
+    // measurement (YMT3_STAMP=1): per-workgroup wall-clock stamps of the decode-step kernels, slot = launch order in the step
+    unsigned long long* stamp_buf = nullptr;   // [STAMP_NODES][STAMP_WGS][2]
+    int stamp_n = 0, stamp_cls[64] = {}, stamp_grid[64] = {};
     // ymt3_ingest: polyphase low-pass per (up, down), built on first use
     struct Resampler { float* taps = nullptr; int up = 1, down = 1, J = 1, Jp = 4, window = 0; long long r = 0; };
     std::map<std::pair<int, int>, Resampler> resamplers;
 };
+
+constexpr int STAMP_NODES = 64, STAMP_WGS = 8192;
+static unsigned long long* next_stamp(ymt3_ctx* c, int cls, int grid) {
+    if (!c->stamp_buf || c->stamp_n >= STAMP_NODES || grid > STAMP_WGS) return nullptr;
+    const int i = c->stamp_n++;
+    c->stamp_cls[i] = cls;
+    c->stamp_grid[i] = grid;
+    return c->stamp_buf + (size_t)i * STAMP_WGS * 2;
+}
 
 enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_COUNT };
 
@@ -300,6 +312,10 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     }
     if (dev_alloc(c, (void**)&c->shared, 8 * sizeof(DecodeShared))) return YMT3_ERR_HIP;
     HIP_TRY(hipMemset(c->shared, 0, 8 * sizeof(DecodeShared)));
+    if (getenv("YMT3_STAMP")) {
+        if (dev_alloc(c, (void**)&c->stamp_buf, (size_t)STAMP_NODES * STAMP_WGS * 2 * sizeof(unsigned long long))) return YMT3_ERR_HIP;
+        HIP_TRY(hipMemset(c->stamp_buf, 0, (size_t)STAMP_NODES * STAMP_WGS * 2 * sizeof(unsigned long long)));
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     const char* ng = getenv("YMT3_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
@@ -475,6 +491,8 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     bf16_t* lm_head;
     GET(h, "dec.lm_head", 1u, &lm_head, (size_t)k.vocab * d);
     (void)w;
+    h->stamp_n = 0;
+    const int mtiles = (R + 15) / 16;
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const LayerW& W = LW[l];
         DecGemmArgs a{};
@@ -483,13 +501,16 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         // self-attention block
         a.x_f32 = h->h_dec; a.gain = W.ln1; a.W = W.wqkv; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
         a.kcache = h->kcache + l * layer_cache; a.vcache = h->vcache + l * layer_cache;
+        a.stamp = next_stamp(h, PC_QKV, a.N / 16 * mtiles);
         PLAUNCH(PC_QKV, launch_dec_gemm(DG_NORM_QKV_CACHE, a, s));
         DecAttnArgs t{};
         t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
         t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
         t.row_pos = a.row_pos;
+        t.stamp = next_stamp(h, PC_SELF_ATTN, R * H);
         PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
         a.a_bf16 = h->dattn; a.W = W.wo; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
+        a.stamp = next_stamp(h, PC_SELF_O, a.N / 16 * mtiles);
         PLAUNCH(PC_SELF_O, launch_dec_gemm(DG_RESID, a, s));
         // cross-attention block: the query projection is fused into the attention kernel (YMT3_NO_FUSEQ=1 keeps
         // the separate skinny GEMM, for A/B measurements)
@@ -508,10 +529,15 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             t.wq = W.wq_c; t.x_f32 = h->h_dec; t.gain = W.ln2; t.ssq = h->ssq; t.ssq_stride = h->maxR; t.eps = k.ln_eps;
         } else {
             a.gain = W.ln2; a.W = W.wq_c; a.N = inner; a.K = d; a.out_bf16 = h->dq;
+            a.stamp = next_stamp(h, PC_CROSS_Q, a.N / 16 * mtiles);
             PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
         }
-        if (!mc) PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
+        if (!mc) {
+            t.stamp = next_stamp(h, PC_CROSS_ATTN, R * H);
+            PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
+        }
         a.a_bf16 = h->dattn; a.W = W.wo_c; a.N = d; a.K = inner;
+        a.stamp = next_stamp(h, PC_CROSS_O, a.N / 16 * mtiles);
         PLAUNCH(PC_CROSS_O, launch_dec_gemm(DG_RESID, a, s));
         // feed-forward block
         if (k.dec_ffn == YMT3_FFN_MOE) {
@@ -523,8 +549,10 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             { ProfScope _ps(h, PC_FFN_WO, s); LAUNCH(launch_moe_stage(3, mo, s)); LAUNCH(launch_moe_stage(4, mo, s)); }
         } else {
             a.gain = W.ln3; a.W = W.wi; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
+            a.stamp = next_stamp(h, PC_FFN_WI, a.N / 16 * mtiles);
             PLAUNCH(PC_FFN_WI, launch_dec_gemm(DG_NORM_BF16_RELU, a, s));
             a.a_bf16 = h->dff; a.W = W.wo2; a.N = d; a.K = k.d_ff;
+            a.stamp = next_stamp(h, PC_FFN_WO, a.N / 16 * mtiles);
             PLAUNCH(PC_FFN_WO, launch_dec_gemm(DG_RESID, a, s));
         }
     }
@@ -532,6 +560,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
     GET(h, "dec.ln_f", 0u, &f, (size_t)d);
     a.x_f32 = h->h_dec; a.gain = f; a.W = lm_head; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
+    a.stamp = next_stamp(h, PC_LM_HEAD, a.N / 16 * mtiles);
     PLAUNCH(PC_LM_HEAD, launch_dec_gemm(DG_NORM_LOGITS, a, s));
     ArgmaxArgs g{};
     g.logits = h->logits; g.h = h->h_dec; g.shared = shared; g.finished = h->finished; g.ssq = h->ssq; g.ssq_stride = h->maxR; g.row0 = row0;
@@ -539,6 +568,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&g.embed), (size_t)k.vocab * d);
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&g.chan_embed), (size_t)k.n_channels * d);
     if (h->slot_mode) { g.row_pos = h->row_pos; g.row_out = h->row_out; }
+    g.stamp = next_stamp(h, PC_ARGMAX, R);
     PLAUNCH(PC_ARGMAX, launch_argmax_embed(g, s));
     return YMT3_OK;
 }
@@ -803,6 +833,38 @@ extern "C" int ymt3_profile_decode(ymt3_handle h, const void* enc_dev, int B, in
     return YMT3_OK;
 }
 static_assert(PC_COUNT <= YMT3_PROFILE_CLASSES, "profile class table");
+
+extern "C" int ymt3_debug_step_stamps(ymt3_handle h, int32_t* cls, int32_t* grid, uint64_t* stats, int* n_kernels) {
+    if (!h || !cls || !grid || !stats || !n_kernels) FAIL(YMT3_ERR_ARG, "null argument");
+    if (!h->stamp_buf) FAIL(YMT3_ERR_UNSUPPORTED, "stamps are recorded only by a handle created with YMT3_STAMP=1 in the environment");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> host((size_t)STAMP_WGS * 2);
+    *n_kernels = h->stamp_n;
+    for (int i = 0; i < h->stamp_n; ++i) {
+        const int gsz = h->stamp_grid[i];
+        HIP_TRY(hipMemcpy(host.data(), h->stamp_buf + (size_t)i * STAMP_WGS * 2, (size_t)gsz * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long in_min = ~0ull, in_max = 0, out_min = ~0ull, out_max = 0;
+        for (int w = 0; w < gsz; ++w) {
+            if (host[2 * w] == 0) continue;                          // a launcher may use fewer workgroups than the slot reserves
+            in_min = std::min(in_min, host[2 * w]); in_max = std::max(in_max, host[2 * w]);
+            out_min = std::min(out_min, host[2 * w + 1]); out_max = std::max(out_max, host[2 * w + 1]);
+        }
+        cls[i] = h->stamp_cls[i]; grid[i] = gsz;
+        stats[4 * i] = in_min; stats[4 * i + 1] = in_max; stats[4 * i + 2] = out_min; stats[4 * i + 3] = out_max;
+    }
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* stamps, int capacity_wgs) {
+    if (!h || !stamps) FAIL(YMT3_ERR_ARG, "null argument");
+    if (!h->stamp_buf) FAIL(YMT3_ERR_UNSUPPORTED, "stamps are recorded only by a handle created with YMT3_STAMP=1 in the environment");
+    if (kernel < 0 || kernel >= h->stamp_n || capacity_wgs < h->stamp_grid[kernel]) FAIL(YMT3_ERR_ARG, "kernel=%d of %d, capacity %d", kernel, h->stamp_n, capacity_wgs);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(stamps, h->stamp_buf + (size_t)kernel * STAMP_WGS * 2, (size_t)h->stamp_grid[kernel] * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return YMT3_OK;
+}
 
 extern "C" int ymt3_set_profile_start(ymt3_handle h, int step0) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");

@@ -170,6 +170,21 @@ class YourMT3:
         _lib.check(self._lib.ymt3_profile_decode(self._handle, _ptr(enc), B, n_steps, stride, _ptr(tokens), ms, cnt, self._stream()))
         return {n: {"ms_total": float(ms[i]), "launches": int(cnt[i])} for i, n in enumerate(self.PROFILE_CLASSES)}
 
+    def step_stamps(self):
+        """Measurement (needs YMT3_STAMP=1 at construction): per kernel of the last decode step, in launch order:
+        (class name, workgroups, first entry, last entry, first exit, last exit) in microseconds from the step's start."""
+        cls = np.zeros(64, np.int32); grid = np.zeros(64, np.int32); st = np.zeros((64, 4), np.uint64)
+        n = ctypes.c_int(0)
+        _lib.check(self._lib.ymt3_debug_step_stamps(self._handle, cls.ctypes.data, grid.ctypes.data, st.ctypes.data, ctypes.byref(n)))
+        t0 = int(st[0, 0])
+        return [(self.PROFILE_CLASSES[int(cls[i])], int(grid[i])) + tuple((int(v) - t0) / 100.0 for v in st[i]) for i in range(n.value)]
+
+    def kernel_stamps(self, kernel: int, grid: int) -> np.ndarray:
+        """Measurement: (grid, 2) raw 100 MHz (entry, exit) stamps of kernel `kernel` of the last decode step."""
+        out = np.zeros((grid, 2), np.uint64)
+        _lib.check(self._lib.ymt3_debug_kernel_stamps(self._handle, int(kernel), out.ctypes.data, int(grid)))
+        return out
+
     def test_gemm(self, a_bf16: torch.Tensor, w_bf16: torch.Tensor) -> torch.Tensor:
         M, K = a_bf16.shape
         N = w_bf16.shape[0]
