@@ -281,37 +281,41 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
 
     // The self-attention cache (up to 805 MB) is read exactly once per step: non-temporal loads keep it
     // from evicting the weights (42 MB) and the cross-attention K/V (201 MB at 64 segments), both
-    // re-read every step, out of the 256 MB Infinity Cache.  Up to 16 x 16-byte loads in flight per lane;
-    // blocks of 64 keys that lie wholly beyond n_keys are skipped wave-uniformly (loads AND math), so
-    // early positions do not pay for the unrolled tail.
+    // re-read every step, out of the 256 MB Infinity Cache.  Up to 12 x 16-byte loads in flight per lane.
     constexpr int U = SELF ? 6 : 4;            // self: 12 loads in flight per lane (8 would spill at 128 VGPRs); cross: 8 x 8 x 4 = 256 frames in one shot
-    auto load_block = [&](u32x4 (&ku)[U], u32x4 (&vu)[U], bool (&ok)[U], int kw, int nblk, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;         // FULL: all U blocks valid, branch-free
+    // Every load of a block -- K, V and the position-bias values -- is issued in STRAIGHT-LINE code, keys beyond n_keys
+    // clamped to the wave's first key and masked in the math: with the loads behind `if (u < nblk)` branches hipcc's
+    // wait-count pass merges the paths and waits for the oldest load with the count of the path that issued the fewest
+    // (vmcnt(1): the whole block), and each bias value became its own load + vmcnt(0) round trip in the score loop.
+    auto load_block = [&](u32x4 (&ku)[U], u32x4 (&vu)[U], bool (&ok)[U], float (&bv)[U], int kw, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;         // FULL: all U blocks valid, no masks
         const int k0 = kw + kg;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int key = k0 + 8 * NW * u;
             ok[u] = FULL || key < n_keys;
-            if (FULL || u < nblk) {
-                const int kc = ok[u] ? key : kw;
-                if constexpr (SELF) {
-                    ku[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV));
-                    vu[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV));
-                } else {
-                    ku[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV);
-                    vu[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV);
-                }
+            const int kc = ok[u] ? key : kw;
+            if constexpr (SELF) {
+                ku[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV));
+                vu[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV));
+            } else {
+                ku[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV);
+                vu[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV);
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (SELF) bv[u] = bias[ok[u] ? n_keys - 1 - (k0 + 8 * NW * u) : 0];
+            else bv[u] = 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // every load of the block is in flight before any math waits
     };
-    auto compute_block = [&](u32x4 (&ku)[U], u32x4 (&vu)[U], bool (&ok)[U], int kw, int nblk, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int k0 = kw + kg;
+    auto compute_block = [&](u32x4 (&ku)[U], u32x4 (&vu)[U], bool (&ok)[U], float (&bv)[U], auto full_tag) {
         float sc[U];
         float mn = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (FULL || u < nblk) {
+            {
                 float s = 0.f;
                 // plain fp32 FMAs on the unpacked halves: v_dot2c_f32_bf16 chains gave O(1) wrong scores on
                 // gfx950 / ROCm 7.2 in this kernel (bisected on hardware), so the packed dot is not used
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
                     s = fmaf(__uint_as_float(qp[j] & 0xffff0000u), __uint_as_float(ku[u][j] & 0xffff0000u), s);
                 }
                 s = sum8(s);
-                if (SELF && ok[u]) s += bias[n_keys - 1 - (k0 + 8 * NW * u)];
+                if constexpr (SELF) s += bv[u];
                 sc[u] = s;
                 if (ok[u]) mn = fmaxf(mn, s);
             }
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
         for (int d = 0; d < 8; ++d) acc[d] *= rescale;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (FULL || u < nblk) {
+            {
                 const float p = ok[u] ? __expf(sc[u] - mn) : 0.f;
                 l += p;
 #pragma unroll
@@ -346,18 +350,18 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
     };
     u32x4 fku[FUSEQ ? U : 1], fvu[FUSEQ ? U : 1];             // FUSEQ: the first K/V block lives across the projection
     bool fok[FUSEQ ? U : 1];
+    float fbv[FUSEQ ? U : 1];
     if constexpr (!FUSEQ) {
-        auto block = [&](int kw, int nblk, auto full_tag) {      // staging registers scoped to one block
+        auto block = [&](int kw, auto full_tag) {                // staging registers scoped to one block
             u32x4 ku[U], vu[U];
             bool ok[U];
-            load_block(ku, vu, ok, kw, nblk, full_tag);
-            compute_block(ku, vu, ok, kw, nblk, full_tag);
+            float bv[U];
+            load_block(ku, vu, ok, bv, kw, full_tag);
+            compute_block(ku, vu, ok, bv, full_tag);
         };
-        for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {      // wave-uniform trip count
-            // wave-uniform: blocks of 64 keys holding at least one valid key for this wave
-            const int nblk = (n_keys - kw + 8 * NW - 1) / (8 * NW);
-            if (n_keys - kw >= 8 * NW * U) block(kw, U, std::true_type{});
-            else block(kw, nblk, std::false_type{});
+        for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {      // wave-uniform trip count: waves with no key skip everything
+            if (n_keys - kw >= 8 * NW * U) block(kw, std::true_type{});
+            else block(kw, std::false_type{});
         }
     } else {
         // every wave's projection operands are requested before ANY wave's K/V: the CU returns vector-memory data in request
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
         for (int u = 0; u < U; ++u) {
             const int key = k0 + 8 * NW * u;
             fok[u] = key < n_keys;
+            fbv[u] = 0.f;
             const int kc = fok[u] ? key : 0;
             fku[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * DKV);
             fvu[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * DKV);
@@ -408,9 +413,8 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
         qp = *reinterpret_cast<const u32x4*>(qs + sub * 8);
         // the block loaded above, then the remaining ones
         for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {
-            const int nb = (n_keys - kw + 8 * NW - 1) / (8 * NW), nblk = nb < U ? nb : U;
-            if (kw != wave * 8) load_block(fku, fvu, fok, kw, nblk, std::false_type{});
-            compute_block(fku, fvu, fok, kw, nblk, std::false_type{});
+            if (kw != wave * 8) load_block(fku, fvu, fok, fbv, kw, std::false_type{});
+            compute_block(fku, fvu, fok, fbv, std::false_type{});
         }
     }
     // merge the 8 key groups of the wave (lanes with equal `sub`)
