@@ -481,6 +481,29 @@ def test_profile_hooks(small):
     assert torch.equal(small.decode(e, 16).cpu(), ref)
 
 
+def test_step_stamps_hook(small, monkeypatch):
+    from yourmt3_amd._lib import YMT3Error
+    with pytest.raises(YMT3Error):
+        small.step_stamps()                                   # handle created without YMT3_STAMP: refused, not garbage
+    monkeypatch.setenv("YMT3_STAMP", "1")
+    m = _model(SMALL)
+    monkeypatch.delenv("YMT3_STAMP")
+    a = O.synthetic_audio(2, SMALL)
+    plain = small.inference(a.cuda(), max_token_length=8)
+    assert torch.equal(m.inference(a.cuda(), max_token_length=8), plain)       # stamping changes no result
+    rows = m.step_stamps()
+    assert len(rows) == 6 * 7 + 2 and rows[0][0] == "qkv_cache_gemm" and rows[-1][0] == "argmax_embed"
+    prev_exit = 0.0
+    for name, grid, in0, in1, out0, out1 in rows:
+        assert grid > 0 and in0 <= in1 and in0 <= out0 <= out1, (name, in0, in1, out0, out1)
+        assert in0 >= prev_exit - 1e-6, name                  # a kernel starts after its predecessor's last workgroup has left
+        prev_exit = out1
+    assert 20.0 < rows[-1][5] < 5000.0                        # one step: tens of microseconds to a few hundred
+    raw = m.kernel_stamps(1, rows[1][1])
+    assert raw.shape == (rows[1][1], 2) and (raw[:, 1] >= raw[:, 0]).all()
+    m.close()
+
+
 def test_bad_blob_and_config_are_rejected():
     import ctypes
     from yourmt3_amd import _lib

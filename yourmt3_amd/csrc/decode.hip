@@ -477,6 +477,15 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     DecodeShared* sh = a.shared;
     const int t = sh->step, n_steps = sh->n_steps, col = t - sh->step0;   // col: index within this call
     const float* row = a.logits + (size_t)r * a.V;
+    // everything thread 0 needs after the argmax is requested now (workgroup-uniform addresses), under the logits loads,
+    // instead of as a chain of round trips behind them
+    int32_t* const tokens_out = sh->tokens_out;
+    const int32_t* const forced = sh->forced;
+    float* const logits_out = sh->logits_out;
+    const int was_finished = a.finished[r];
+    const int forced_tok = forced ? forced[(size_t)r * n_steps + col] : 0;
+    const int pos0 = a.row_pos ? a.row_pos[r] : 0;
+    const long long out0 = a.row_pos ? a.row_out[r] : 0;
 
     float bv = -3.4e38f;
     int bi = 0x7fffffff;
@@ -499,9 +508,9 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
         for (int w = 1; w < 4; ++w)
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
         int feed = a.pad_id;
-        if (!a.finished[r]) {
-            const int p = a.row_pos[r];
-            sh->tokens_out[a.row_out[r] + p] = bi;
+        if (!was_finished) {
+            const int p = pos0;
+            tokens_out[out0 + p] = bi;
             if ((a.eos_id >= 0 && bi == a.eos_id) || p + 1 >= n_steps) a.finished[r] = 1;
             else a.row_pos[r] = p + 1;
             feed = bi;
@@ -513,11 +522,11 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
         int tok = bi;
         if (a.eos_id >= 0) {
-            if (a.finished[r]) tok = a.pad_id;
+            if (was_finished) tok = a.pad_id;
             else if (tok == a.eos_id) a.finished[r] = 1;
         }
-        sh->tokens_out[(size_t)r * n_steps + col] = tok;
-        int feed = sh->forced ? sh->forced[(size_t)r * n_steps + col] : tok;
+        tokens_out[(size_t)r * n_steps + col] = tok;
+        int feed = forced ? forced_tok : tok;
         s_feed = feed < 0 ? 0 : (feed >= a.V ? a.V - 1 : feed);       // caller-supplied ids must not index outside the table
     }
     __syncthreads();
@@ -525,14 +534,14 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     const bf16_t* e = a.embed + (size_t)feed * a.d;
     const bf16_t* c = a.chan_embed ? a.chan_embed + (size_t)(r % a.n_channels) * a.d : nullptr;
     embed_row(a, r, e, c, sv);
-    if (sh->logits_out && !a.row_pos) {
-        float* dst = sh->logits_out + ((size_t)r * n_steps + col) * a.V;
+    if (logits_out && !a.row_pos) {
+        float* dst = logits_out + ((size_t)r * n_steps + col) * a.V;
         for (int i = tid; i < a.V; i += 256) dst[i] = row[i];
     }
     // the last workgroup to finish advances the position; every workgroup has read `t` by then
     __syncthreads();
     if (tid == 0) {
-        __threadfence();
+        if (a.eos_id >= 0) __threadfence();      // only the flags the last arriver counts below need to be visible to it
         const int old = atomicAdd(&sh->done_count, 1);
         if (old == (int)gridDim.x - 1) {
             sh->done_count = 0;
