@@ -9,8 +9,9 @@ from yourmt3_amd.audio import synthetic_segments
 from yourmt3_amd.config import baseline_config
 from yourmt3_amd.model import YourMT3
 cfg = baseline_config(1)
-m = YourMT3(cfg, max_batch=64)
-a = torch.from_numpy(synthetic_segments(64, cfg.segment_samples)).cuda()
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+m = YourMT3(cfg, max_batch=B)
+a = torch.from_numpy(synthetic_segments(B, cfg.segment_samples)).cuda()
 enc = m.encode(m.logmel(a))
 n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 m.decode(enc, n_steps); torch.cuda.synchronize()
@@ -29,7 +30,7 @@ print(f"step: {rows[-1][5] - rows[0][2]:.2f} us = spans {tot_span:.2f} + gaps {t
 
 # distribution of workgroup exit times inside the two attention kernels of layer 3 (launch order 22 = self, 24 = cross)
 import numpy as np
-for k in (22, 24):
+for k in ((22, 24) if B == 64 else ()):
     name, grid = rows[k][0], rows[k][1]
     st = m.kernel_stamps(k, grid).astype(np.int64)
     st = st[st[:, 0] > 0]                                   # a launcher may use fewer workgroups than the slot reserves

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     if constexpr (MODE == DG_RESID) {
         if (live) hold = *reinterpret_cast<const float2*>(a.out_f32 + (size_t)m * a.N + n);   // prefetch the RMW operand
     }
+    int step = 0;                                // cache position of the KV append: requested now, not as a round trip in the epilogue
+    if constexpr (MODE == DG_NORM_QKV_CACHE) step = a.row_pos ? a.row_pos[m < m_end ? m : m_end - 1] : a.shared->step;
 
     f32x4 acc[MT];
 #pragma unroll
@@ -209,7 +211,6 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             if (n < inner) {
                 *reinterpret_cast<uint32_t*>(a.out_bf16 + (size_t)m * inner + n) = pk;
             } else {
-                const int step = a.row_pos ? a.row_pos[m] : a.shared->step;
                 const int nn = n - inner, kv = nn / inner, hh = (nn % inner) >> 6, dd = nn & 63;
                 bf16_t* cache = kv ? a.vcache : a.kcache;
                 *reinterpret_cast<uint32_t*>(cache + (((size_t)m * a.H + hh) * a.L + step) * DKV + dd) = pk;
