@@ -56,25 +56,29 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // The RMS norm needs sum(x^2) over the FULL row, which no single wave sees: it is carried between
 // kernels as per-row partial sums `ssq[tile][row]` written by whoever last wrote the residual stream
 // (the 32 column tiles of the RESID epilogue, or the embedding gather) and summed in a fixed order.
-template <int MODE, int K, int MT>
+// NT = 16-column tiles per workgroup (1 or 2): two halve the workgroup count of the wide projections (QKV, FFN-in, lm_head)
+// to about one per CU -- at two per CU the second one's operands queue behind the first's and the kernel's last exit came
+// 1.1 us after its first (profiles/r01_step_stamps.txt) -- and the activation strip is read once for both.
+template <int MODE, int K, int NT>
 __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     constexpr bool NORM = (MODE != DG_RESID);
     constexpr int KW = K / 8;            // K slice per wave
     constexpr int KS = KW / 32;          // MFMA k-steps per wave
-    constexpr int ROWS = 16 * MT;
+    constexpr int ROWS = 16, COLS = 16 * NT;
     constexpr int PITCH = KW * 2 + 16;   // bytes per strip row (bf16 slice + 16 B pad against bank conflicts)
     constexpr int STRIP = 16 * PITCH;    // one operand strip (16 rows) of one wave
+    static_assert(MODE != DG_RESID || NT == 1, "the RESID epilogue writes one sum(h^2) partial per 16-column tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     STAMP_IN(a);
-    float* red = reinterpret_cast<float*>(smem);                    // [8][ROWS][16]
-    float* sscale = red + 8 * ROWS * 16;                            // [ROWS]
-    char* strips = smem + (8 * ROWS * 16 + ROWS) * 4;               // MT == 1: [8 waves][A strip | W strip]
+    float* red = reinterpret_cast<float*>(smem);                    // [8][ROWS][COLS]
+    float* sscale = red + 8 * ROWS * COLS;                          // [ROWS]
+    char* strips = smem + (8 * ROWS * COLS + ROWS) * 4;             // [8 waves][A strip | NT W strips]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     // block -> (n tile, m tile): blocks with equal blockIdx % 8 (one XCD under round-robin placement;
     // speed only) walk the m tiles of one n tile back to back
-    const int n_mt = (a.R + ROWS - 1) / ROWS, n_nt = a.N / 16;
+    const int n_mt = (a.R + ROWS - 1) / ROWS, n_nt = a.N / COLS;
     int nt_idx, mt_idx;
     if ((n_nt & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -84,11 +88,11 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
         mt_idx = blockIdx.x % n_mt;
         nt_idx = blockIdx.x / n_mt;
     }
-    const int n0 = nt_idx * 16, m0 = a.row0 + mt_idx * ROWS, m_end = a.row0 + a.R;
+    const int n0 = nt_idx * COLS, m0 = a.row0 + mt_idx * ROWS, m_end = a.row0 + a.R;
 
     // epilogue ownership: thread -> (row mr, 2 columns nq)
-    const bool epi = tid < ROWS * 8;
-    const int mr = tid >> 3, nq = (tid & 7) * 2;
+    const bool epi = tid < ROWS * 8 * NT;
+    const int mr = tid / (8 * NT), nq = (tid % (8 * NT)) * 2;
     const int m = m0 + mr, n = n0 + nq;
     const bool live = epi && m < m_end;
     float2 hold = make_float2(0.f, 0.f);
@@ -98,15 +102,15 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     int step = 0;                                // cache position of the KV append: requested now, not as a round trip in the epilogue
     if constexpr (MODE == DG_NORM_QKV_CACHE) step = a.row_pos ? a.row_pos[m < m_end ? m : m_end - 1] : a.shared->step;
 
-    f32x4 acc[MT];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     {
-        char* sA = strips + wave * 2 * STRIP;
+        char* sA = strips + wave * (1 + NT) * STRIP;
         char* sW = sA + STRIP;
         // weight slice: LPRW lanes cover one row's KW bf16
-        constexpr int LPRW = KW * 2 / 16, RPIW = 64 / LPRW, NIW = 16 / RPIW;
+        constexpr int LPRW = KW * 2 / 16, RPIW = 64 / LPRW, NIA = 16 / RPIW, NIW = NIA * NT;
         u32x4 wv[NIW];
 #pragma unroll
         for (int i = 0; i < NIW; ++i) {
@@ -124,8 +128,8 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             }
             const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gain + wave * KW + (lane % LPRX) * 4);
             float ss = 0.f;
-            if (epi) {
-                const int mm = m < m_end ? m : m_end - 1;
+            if (tid < ROWS * 8) {                                    // 8 threads per row, 4 of the 32 partials each
+                const int mm = m0 + (tid >> 3) < m_end ? m0 + (tid >> 3) : m_end - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ss += a.ssq[(size_t)((tid & 7) * 4 + j) * a.ssq_stride + mm];
             }
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             ss += __shfl_xor(ss, 1, 64);
             ss += __shfl_xor(ss, 2, 64);
             ss += __shfl_xor(ss, 4, 64);
-            if (epi && (tid & 7) == 0) sscale[mr] = rsqrtf(ss / (float)K + a.eps);
+            if (tid < ROWS * 8 && (tid & 7) == 0) sscale[tid >> 3] = rsqrtf(ss / (float)K + a.eps);
 #pragma unroll
             for (int i = 0; i < NIW; ++i)
                 *reinterpret_cast<u32x4*>(sW + (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16) = wv[i];
@@ -147,7 +151,6 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
                                pack_bf16x2(xv[i][2] * sc * gv[2], xv[i][3] * sc * gv[3]));
             }
         } else {
-            constexpr int NIA = NIW;
             u32x4 av[NIA];
 #pragma unroll
             for (int i = 0; i < NIA; ++i) {
@@ -160,31 +163,34 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             for (int i = 0; i < NIW; ++i) {
                 const int off = (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16;
                 *reinterpret_cast<u32x4*>(sW + off) = wv[i];
-                *reinterpret_cast<u32x4*>(sA + off) = av[i];
+                if (i < NIA) *reinterpret_cast<u32x4*>(sA + off) = av[i];
             }
         }
         // fragment order read-back (wave-private strips: in-order LDS, no barrier)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int off = li * PITCH + (ks * 32 + g * 8) * 2;
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + off);
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + off);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[0], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + c * STRIP + off);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[c], 0, 0, 0);
+            }
         }
     }
 
-    // fixed-order cross-wave reduction: red[wave][row][n (16)]
+    // fixed-order cross-wave reduction: red[wave][row][n (COLS)]
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        *reinterpret_cast<float4*>(red + ((wave * ROWS + mt * 16 + li) * 16 + g * 4)) =
-            make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    for (int c = 0; c < NT; ++c)
+        *reinterpret_cast<float4*>(red + ((wave * ROWS + li) * COLS + c * 16 + g * 4)) =
+            make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
     __syncthreads();
     float2 s = make_float2(0.f, 0.f);
     if (epi) {
-        s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
+        s = *reinterpret_cast<const float2*>(red + (mr * COLS + nq));
 #pragma unroll
         for (int w = 1; w < 8; ++w) {
-            const float2 t = *reinterpret_cast<const float2*>(red + ((w * ROWS + mr) * 16 + nq));
+            const float2 t = *reinterpret_cast<const float2*>(red + ((w * ROWS + mr) * COLS + nq));
             s.x += t.x; s.y += t.y;
         }
     }
@@ -602,19 +608,28 @@ __global__ void pad_tail_kernel(int32_t* tokens_out, int row0, int n_steps, int 
     for (int i = from + threadIdx.x; i < n_steps; i += blockDim.x) row[i] = pad_id;
 }
 
-template <int MODE, int K>
+template <int MODE, int K, int NT>
 constexpr size_t dg_lds_bytes() {
-    return (size_t)(8 * 16 * 16 + 16) * 4 + (size_t)8 * 2 * 16 * (K / 8 * 2 + 16);
+    return (size_t)(8 * 16 * 16 * NT + 16) * 4 + (size_t)8 * (1 + NT) * 16 * (K / 8 * 2 + 16);
 }
 
-template <int MODE, int K>
+template <int MODE, int K, int NT = 1>
 int launch_dg(const DecGemmArgs& a, hipStream_t stream) {
     if (a.W == nullptr)     // attribute-only call from init_decode_kernels(): > 64 KB of dynamic LDS needs opting in
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, 1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K>()) == hipSuccess ? 0 : -2;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, NT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K, NT>()) == hipSuccess ? 0 : -2;
     if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;   // the norm consumers sum exactly SSQ_TILES partials
-    dec_gemm_kernel<MODE, K, 1><<<(a.N / 16) * ((a.R + 15) / 16), 512, dg_lds_bytes<MODE, K>(), stream>>>(a);
+    dec_gemm_kernel<MODE, K, NT><<<(a.N / (16 * NT)) * ((a.R + 15) / 16), 512, dg_lds_bytes<MODE, K, NT>(), stream>>>(a);
     return 0;
+}
+
+// wide projections: 32 columns per workgroup once 16-column tiles would put more than one workgroup on a CU
+template <int MODE>
+int launch_dg_wide(const DecGemmArgs& a, hipStream_t stream) {
+    static const bool narrow = getenv("YMT3_DEC_GEMM_NARROW") != nullptr;      // A/B timing only
+    const int wgs16 = (a.N / 16) * ((a.R + 15) / 16);
+    if (!narrow && a.N % 32 == 0 && wgs16 > 320) return launch_dg<MODE, 512, 2>(a, stream);
+    return launch_dg<MODE, 512, 1>(a, stream);
 }
 
 }  // namespace
@@ -629,6 +644,10 @@ int init_decode_kernels() {
     rc |= launch_dg<DG_NORM_BF16, 512>(z, nullptr);
     rc |= launch_dg<DG_NORM_BF16_RELU, 512>(z, nullptr);
     rc |= launch_dg<DG_NORM_LOGITS, 512>(z, nullptr);
+    rc |= launch_dg<DG_NORM_QKV_CACHE, 512, 2>(z, nullptr);
+    rc |= launch_dg<DG_NORM_BF16, 512, 2>(z, nullptr);
+    rc |= launch_dg<DG_NORM_BF16_RELU, 512, 2>(z, nullptr);
+    rc |= launch_dg<DG_NORM_LOGITS, 512, 2>(z, nullptr);
     return rc;
 }
 
@@ -643,10 +662,10 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
     }
     if (a.K != 512) return -1;
     switch (mode) {
-        case DG_NORM_QKV_CACHE: return launch_dg<DG_NORM_QKV_CACHE, 512>(a, stream);
-        case DG_NORM_BF16: return launch_dg<DG_NORM_BF16, 512>(a, stream);
-        case DG_NORM_BF16_RELU: return launch_dg<DG_NORM_BF16_RELU, 512>(a, stream);
-        case DG_NORM_LOGITS: return launch_dg<DG_NORM_LOGITS, 512>(a, stream);
+        case DG_NORM_QKV_CACHE: return launch_dg_wide<DG_NORM_QKV_CACHE>(a, stream);
+        case DG_NORM_BF16: return launch_dg_wide<DG_NORM_BF16>(a, stream);
+        case DG_NORM_BF16_RELU: return launch_dg_wide<DG_NORM_BF16_RELU>(a, stream);
+        case DG_NORM_LOGITS: return launch_dg_wide<DG_NORM_LOGITS>(a, stream);
         default: return -1;
     }
 }
