@@ -2,8 +2,10 @@
 // head), no 1/sqrt(d) scale (TP: transformers/models/t5/modeling_t5.py:196-197), bias added
 // before the softmax (:159-167), one bias table shared by all layers (:739-742).
 //
-// One workgroup = one (segment, head, 64-query tile); 4 waves x 16 queries.  K and V of the whole
-// segment (T <= 512 keys x 64) live in LDS.  Scores are computed TRANSPOSED, S^T = K Q^T, with
+// One workgroup = one (segment, head): K and V of the whole segment (T <= 512 keys x 64) are staged in LDS ONCE and two
+// groups of four waves walk the segment's even / odd 64-query tiles (16 queries per wave), the next tile's Q fragments in flight under the
+// current tile's math.  (One workgroup per query tile re-staged the same 64 KB four times: 134 MB of L2 -> LDS traffic per
+// layer for 8.6 GFLOP; the kernel was bound by that, 38 us.)  Scores are computed TRANSPOSED, S^T = K Q^T, with
 // v_mfma_f32_16x16x32_bf16 so that each lane owns ONE query column and 4 consecutive keys per
 // accumulator: the softmax reductions are lane-local plus two shuffles, and the exponentials,
 // rounded to bf16, are already the B operand of the second product O^T = V^T P^T.  V^T fragments come
@@ -23,36 +25,59 @@ constexpr int ROWB = 144;   // LDS row pitch in bytes (128 + 16 pad: spreads row
 // q rows: q + (b*T + t) * ldq + h*64;  k / v rows: k|v + (b*T + t) * ldkv + h*64.  The T5 encoder passes one fused
 // qkv buffer (k = qkv + inner, v = qkv + 2*inner, ldq = ldkv = 3*inner); the latent cross-attention (a9) passes
 // the latent queries and the frame K/V as separate buffers.
+template <int T> constexpr int enc_attn_threads() { return T >= 512 ? 256 : 512; }   // 512 keys: 128 score registers per lane, one wave per SIMD
+
 template <int T>
-__global__ __launch_bounds__(256) void enc_attn_kernel(const bf16_t* __restrict__ qp, int ldq, const bf16_t* __restrict__ kp,
+__global__ __launch_bounds__(enc_attn_threads<T>()) void enc_attn_kernel(const bf16_t* __restrict__ qp, int ldq, const bf16_t* __restrict__ kp,
                                                        const bf16_t* __restrict__ vp, int ldkv,
                                                        const float* __restrict__ bias_off, bf16_t* __restrict__ out, int H) {
-    constexpr int NT = T / 16;
+    constexpr int NT = T / 16, NTH = enc_attn_threads<T>(), NG = NTH / 256;   // NG groups of four waves share the query tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sV = smem + T * ROWB;
     float* sB = reinterpret_cast<float*>(smem + 2 * T * ROWB);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) & 3, half = tid >> 8;       // waves 0-3 take query tiles 0, NG, ..; waves 4-7 (if any) tiles 1, 1 + NG, ..
+    const int h = blockIdx.y, b = blockIdx.z;
     const int inner = H * DKV;
     const size_t kvoff = (size_t)b * T * ldkv + h * DKV;
 
-    for (int idx = tid; idx < T * 8; idx += 256) {
-        const int row = idx >> 3, ch = idx & 7;
-        const size_t o = kvoff + (size_t)row * ldkv + ch * 8;
-        *reinterpret_cast<uint4*>(sK + row * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(kp + o);
-        *reinterpret_cast<uint4*>(sV + row * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(vp + o);
+    {
+        // all of this thread's K/V chunks are requested before the first is written to LDS (one memory round trip)
+        constexpr int NCH = (T * 8 + NTH - 1) / NTH;
+        uint4 kc[NCH], vc[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * NTH, row = (idx < T * 8 ? idx : 0) >> 3, ch = idx & 7;
+            const size_t o = kvoff + (size_t)row * ldkv + ch * 8;
+            kc[i] = *reinterpret_cast<const uint4*>(kp + o);
+            vc[i] = *reinterpret_cast<const uint4*>(vp + o);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * NTH, row = idx >> 3, ch = idx & 7;
+            if (idx < T * 8) {
+                *reinterpret_cast<uint4*>(sK + row * ROWB + ch * 16) = kc[i];
+                *reinterpret_cast<uint4*>(sV + row * ROWB + ch * 16) = vc[i];
+            }
+        }
     }
-    for (int i = tid; i < 2 * T - 1; i += 256) sB[i] = bias_off[(size_t)h * (2 * T - 1) + i];
+    for (int i = tid; i < 2 * T - 1; i += NTH) sB[i] = bias_off[(size_t)h * (2 * T - 1) + i];
 
     const int g = lane >> 4, li = lane & 15;
-    const int q = qt * 64 + wave * 16 + li;             // this lane's query (position in segment)
-    bf16x8 qf[2];
+    auto load_q = [&](int qt, bf16x8 (&qf)[2]) {
+        const int q = qt * 64 + wave * 16 + li;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-        qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + ((size_t)b * T + q) * ldq + h * DKV + ks * 32 + g * 8));
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + ((size_t)b * T + q) * ldq + h * DKV + ks * 32 + g * 8));
+    };
+    bf16x8 qf[2], qn[2];
+    if (half < T / 64) load_q(half, qf);
     __syncthreads();
+    for (int qt = half; qt < T / 64; qt += NG) {
+    const int q = qt * 64 + wave * 16 + li;             // this lane's query (position in segment)
+    if (qt + NG < T / 64) load_q(qt + NG, qn);
 
     // S^T tiles: lane -> query q, keys kt*16 + 4g + r
     f32x4 s[NT];
@@ -120,6 +145,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16_t* __restrict_
         const uint2 pk = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
         *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) = pk;
     }
+    qf[0] = qn[0]; qf[1] = qn[1];
+    }
 }
 
 template <int T>
@@ -129,7 +156,7 @@ int launch_t(const bf16_t* q, int ldq, const bf16_t* k, const bf16_t* v, int ldk
     if (q == nullptr)       // attribute-only call from init_enc_attn_kernels()
         return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -2;
-    enc_attn_kernel<T><<<dim3(T / 64, H, B), 256, lds, stream>>>(q, ldq, k, v, ldkv, bias_off, out, H);
+    enc_attn_kernel<T><<<dim3(1, H, B), enc_attn_threads<T>(), lds, stream>>>(q, ldq, k, v, ldkv, bias_off, out, H);
     return 0;
 }
 
