@@ -399,6 +399,9 @@ def test_full_size_properties_baseline_config_1():
     eos = int(t1[5, 0, 100])
     m2 = _model(cfg.with_(eos_id=eos), max_batch=64)
     t2 = m2.inference(a).cpu()
+    # continuous batching at full size: 64 segments through 24 slots (ragged refills), and through all 64 -- same ids
+    assert torch.equal(m2.inference_stream(a, slots=24, interval=16).cpu(), t2)
+    assert torch.equal(m2.inference_stream(a, slots=64, interval=32).cpu(), t2)
     m2.close()
     t1c = t1.cpu()
     for b in range(64):
