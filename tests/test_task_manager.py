@@ -201,3 +201,66 @@ def test_transcribe_flow_writes_the_expected_midi(tmp_path):
     assert abs(back[1].onset - 1.5) < 6e-3 and abs(back[1].offset - 3.0) < 6e-3
     with pytest.raises(ValueError):
         transcribe(model, audio, task_manager=TaskManager("mc13_full_plus_256"))
+
+
+# ------------------------------------------------------------------------------------------------ property tests
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.lists(st.lists(st.integers(min_value=-5, max_value=1600), min_size=0, max_size=96), min_size=1, max_size=4))
+def test_detokenizer_accepts_any_id_stream(segments):
+    """Whatever ids the model emits -- out of vocabulary, negative, offsets without onsets, programs without pitches,
+    shifts past the segment -- detokenising never raises, reports malformed tokens as a count, and yields well-formed notes."""
+    tm = TaskManager()
+    L = max(1, max(len(s) for s in segments))
+    arr = np.full((len(segments), 1, L), PAD, dtype=np.int32)
+    for i, sgm in enumerate(segments):
+        arr[i, 0, :len(sgm)] = sgm
+    starts = [i * SEG for i in range(len(segments))]
+    for i, sgm in enumerate(segments):
+        ev, ties, bad = tm.tokenizer.decode_segment(list(arr[i, 0]), starts[i])
+        assert bad >= 0 and all(isinstance(e, NoteEvent) for e in ev)
+        assert all(e.time >= starts[i] - 1e-9 for e in ev)
+    notes = tm.tokens_to_notes([arr], starts, end_sec=len(segments) * SEG)
+    for n in notes:
+        assert 0 <= n.pitch < 128 and n.offset >= n.onset >= 0.0
+        assert n.is_drum == (n.program == DRUM_PROGRAM)
+    data = notes_to_midi_bytes(notes)
+    back = read_midi_notes(data)                      # same-pitch notes that overlap or coincide are merged by the writer
+    assert data[:4] == b"MThd" and len(back) <= len(notes) and (len(back) > 0) == (len(notes) > 0)
+    assert all(n.offset > n.onset for n in back)
+
+
+_note = st.tuples(st.integers(0, 740), st.integers(5, 300), st.sampled_from([0, 24, 40, 129]), st.integers(21, 108), st.booleans())
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(_note, min_size=1, max_size=40))
+def test_tokenise_detokenise_roundtrip_property(raw):
+    """Random note sets over 4 segments (10 ms grid, ties across segment boundaries, drums): tokenise per segment ->
+    detokenise -> the same notes, onsets and offsets within half a grid step."""
+    tm = TaskManager()
+    notes, busy = [], {}
+    for on_cs, dur_cs, prog, pitch, drum in sorted(raw):
+        on = on_cs / 100.0
+        if drum:
+            notes.append(Note(on, on + 0.01, True, DRUM_PROGRAM, 35 + pitch % 10))
+            continue
+        off = min(on + dur_cs / 100.0, 4 * SEG - 0.05)
+        k = (prog, pitch)
+        if off <= on + 0.02 or (k in busy and busy[k] >= on - 0.02):
+            continue                                  # overlapping notes of one (program, pitch) cannot round-trip exactly
+        busy[k] = off
+        notes.append(Note(on, off, False, prog, pitch))
+    if not notes:
+        return
+    toks = _tokenize(tm, notes, 4, 1024)
+    got = tm.tokens_to_notes([toks[:, None, :]], [i * SEG for i in range(4)], end_sec=4 * SEG)
+    key = lambda x: (x.is_drum, x.program, x.pitch, round(x.onset, 2))
+    # drum hits on the same pitch and grid step collapse to one event in the token stream: compare sets of keys
+    assert {key(n) for n in got} == {key(Note(_grid(n.onset, SEG * int(n.onset // SEG)), n.offset, n.is_drum, n.program, n.pitch)) for n in notes}
+    for g in got:
+        if not g.is_drum:
+            m = [n for n in notes if (n.program, n.pitch) == (g.program, g.pitch) and abs(n.onset - g.onset) <= 0.0051]
+            assert m and abs(m[0].offset - g.offset) <= 0.0051

@@ -32,9 +32,22 @@ def notes_to_midi_bytes(notes: Sequence[Note]) -> bytes:
     for i, (prog, ns) in enumerate(sorted(by_prog.items())):
         ch = 9 if prog == DRUM_PROGRAM else melodic_channels[i % 15]
         ev = []
-        for n in ns:
-            ev.append((_ticks(n.onset), 1, n.pitch, n.velocity))
-            ev.append((max(_ticks(n.offset), _ticks(n.onset) + 1), 0, n.pitch, 0))
+        # one voice per (channel, pitch): a note still sounding when the same pitch starts again ends at that onset, and a
+        # second note starting on the same tick is dropped -- otherwise the note-ons and note-offs of the file do not pair up
+        spans: Dict[int, List[List[int]]] = {}
+        for n in sorted(ns, key=lambda x: (x.pitch, x.onset, x.offset)):
+            on, off = _ticks(n.onset), max(_ticks(n.offset), _ticks(n.onset) + 1)
+            sp = spans.setdefault(n.pitch, [])
+            if sp and sp[-1][0] == on:
+                sp[-1][1] = max(sp[-1][1], off)
+                continue
+            if sp and sp[-1][1] > on:
+                sp[-1][1] = on
+            sp.append([on, off, n.velocity])
+        for pitch, sp in spans.items():
+            for on, off, vel in sp:
+                ev.append((on, 1, pitch, vel))
+                ev.append((off, 0, pitch, 0))
         ev.sort(key=lambda e: (e[0], e[1]))            # offsets before onsets at the same tick
         body = bytearray()
         if prog != DRUM_PROGRAM:

@@ -121,7 +121,12 @@ class NoteEventTokenizer:
             elif ev.type == "program":
                 prog = ev.value
             elif ev.type == "pitch":
-                if in_tie:
+                if prog == DRUM_PROGRAM:                    # a pitch under the drum program is a drum hit: no ties, no offsets
+                    if in_tie:
+                        bad += 1
+                    elif vel:
+                        events.append(NoteEvent(start_sec + step / c.steps_per_second, True, DRUM_PROGRAM, 1, ev.value))
+                elif in_tie:
                     ties.append((prog, ev.value))
                 else:
                     events.append(NoteEvent(start_sec + step / c.steps_per_second, False, prog, vel, ev.value))
@@ -138,10 +143,12 @@ def note_events_to_notes(segments: Sequence[Tuple[float, List[NoteEvent], List[T
 
     A note sounding at a segment boundary stays open only if the next segment's tie section lists it;
     otherwise it is closed at that segment's start.  Offsets without an onset are dropped; a repeated
-    onset re-triggers (closes the old note at the new onset).
+    onset re-triggers (closes the old note at the new onset); a drum hit repeated at the same time and
+    pitch (the model emitting a token twice) is one hit.
     """
     active: Dict[Tuple[int, int], float] = {}
     notes: List[Note] = []
+    drum_hits = set()
     for start, events, ties in sorted(segments, key=lambda s: s[0]):
         tie_set = set(ties)
         for key in [k for k in active if k not in tie_set]:
@@ -150,7 +157,9 @@ def note_events_to_notes(segments: Sequence[Tuple[float, List[NoteEvent], List[T
                 notes.append(Note(on, start, False, key[0], key[1]))
         for ev in sorted(events):
             if ev.is_drum:
-                notes.append(Note(ev.time, ev.time + DRUM_NOTE_SEC, True, DRUM_PROGRAM, ev.pitch))
+                if (ev.time, ev.pitch) not in drum_hits:
+                    drum_hits.add((ev.time, ev.pitch))
+                    notes.append(Note(ev.time, ev.time + DRUM_NOTE_SEC, True, DRUM_PROGRAM, ev.pitch))
                 continue
             key = (ev.program, ev.pitch)
             if ev.velocity:
