@@ -532,6 +532,19 @@ def test_bad_blob_and_config_are_rejected():
     assert rc == 2 and "dec.3.wo" in msg
     rc, msg = create(pack_blob({k: v for k, v in full.items() if k != "fe.window"}))
     assert rc == 2 and "fe.window" in msg
+    # corrupt directory entries: offset + size wrapping around 2^64, an entry pointing into the header, a truncated file
+    import struct
+    good = pack_blob(full)
+    n_entries = struct.unpack_from("<I", good, 12)[0]
+    for off, size in ((2 ** 64 - 16, 64), (16, 64), (len(good) - 16, 2 ** 63)):
+        bad = bytearray(good)
+        struct.pack_into("<QQ", bad, 16 + 5 * 88 + 72, off, size)                 # entry 5: {name[48], dtype, ndim, shape[4], offset, nbytes}
+        rc, msg = create(bytes(bad))
+        assert rc == 2 and "out of bounds" in msg, (off, size, rc, msg)
+    rc, msg = create(good[:16 + n_entries * 88 - 8])
+    assert rc == 2 and "truncated" in msg
+    rc, msg = create(good[:len(good) // 2])
+    assert rc == 2
     rc, msg = create(pack_blob(full), cfg.with_(d_kv=32, n_heads=16))
     assert rc == 4
     rc, msg = create(pack_blob(full), cfg.with_(segment_samples=8191 + 128))      # 65 frames: not a multiple of 64

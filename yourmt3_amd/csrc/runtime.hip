@@ -182,7 +182,9 @@ static int parse_blob(ymt3_ctx* c, const void* blob, size_t nbytes) {
     for (uint32_t i = 0; i < n; ++i) {
         BlobEntry e;
         memcpy(&e, b + 16 + (size_t)i * sizeof(BlobEntry), sizeof(e));
-        if (e.offset % 16 || e.offset + e.nbytes > nbytes) FAIL(YMT3_ERR_BLOB, "tensor %u out of bounds / misaligned", i);
+        const size_t header_end = 16 + (size_t)n * sizeof(BlobEntry);
+        if (e.offset % 16 || e.offset < header_end || e.offset > nbytes || e.nbytes > nbytes - e.offset)     // no wrap-around
+            FAIL(YMT3_ERR_BLOB, "tensor %u out of bounds / misaligned", i);
         e.name[47] = 0;
         Tensor t;
         t.dev = c->blob_dev + e.offset;
