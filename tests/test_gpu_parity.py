@@ -545,6 +545,8 @@ def test_bad_blob_and_config_are_rejected():
     assert rc == 2 and "truncated" in msg
     rc, msg = create(good[:len(good) // 2])
     assert rc == 2
+    for bad_cfg in (cfg.with_(hop=0), cfg.with_(n_dec_layers=0), cfg.with_(vocab=-16), cfg.with_(max_decode_len=10 ** 6)):
+        assert create(good, bad_cfg)[0] == 1                                        # YMT3_ERR_ARG, not a crash
     rc, msg = create(pack_blob(full), cfg.with_(d_kv=32, n_heads=16))
     assert rc == 4
     rc, msg = create(pack_blob(full), cfg.with_(segment_samples=8191 + 128))      # 65 frames: not a multiple of 64

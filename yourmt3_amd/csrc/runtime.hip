@@ -231,6 +231,10 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (k.dec_ffn == YMT3_FFN_MOE && (k.moe_top_k != 2 || k.n_experts < 2 || k.n_experts > 16 || k.d_ff != 2048))
         FAIL(YMT3_ERR_UNSUPPORTED, "MoE FFN needs top_k = 2, 2..16 experts, d_ff = 2048");
     if (k.max_batch <= 0 || k.n_channels <= 0 || k.max_decode_len <= 0) FAIL(YMT3_ERR_ARG, "bad max_batch / n_channels / max_decode_len");
+    if (k.hop <= 0 || k.sample_rate <= 0 || k.segment_samples <= 0 || k.n_fft <= 0 || k.n_mels <= 0 || k.vocab <= 0 || k.d_ff <= 0 ||
+        k.n_enc_layers < 0 || k.n_dec_layers <= 0 || k.n_enc_layers > 64 || k.n_dec_layers > 64 || k.n_channels > 64 ||
+        k.max_decode_len > 65536 || (long long)k.max_batch * k.n_channels > 65536)
+        FAIL(YMT3_ERR_ARG, "a size field of the config is zero, negative or absurd");
     c->T = 1 + k.segment_samples / k.hop;
     c->inner = k.n_heads * k.d_kv;
     c->maxB = k.max_batch;
