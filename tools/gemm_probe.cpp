@@ -22,7 +22,7 @@ static int run(const char* name, int epi, int M, int N, int K, hipStream_t st) {
     for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (bf16_t)(0x3c00 + ((x >> 16) & 0x3ff) + ((x >> 31) << 15)); }
     CK(hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
     CK(hipMemset(C, 0, (size_t)M * N * 4));
-    GemmArgs g{A, W, C, nullptr, M, N, K, K, K, N, 256, 8, M / 256};
+    GemmArgs g{A, W, C, nullptr, M, N, K, K, K, N, 256, 8, M / 256 > 0 ? M / 256 : 1};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) if (launch_gemm(epi, g, st)) { fprintf(stderr, "launch rejected\n"); return 1; }
     CK(hipStreamSynchronize(st));
@@ -46,5 +46,13 @@ int main() {
     run("wo   (fp32 resid)", EPI_RESID, 16384, 512, 2048, st);
     run("ckv  (head-major bf16)", EPI_KV_HEADMAJOR, 16384, 6144, 512, st);
     run("big square", EPI_BF16, 8192, 8192, 8192, st);
+    // decode-side shapes of the many-row configs (832 rows = 64 segments x 13 channels; 256 rows): what the 128 x 128 encoder
+    // kernel makes of them, to size a mid-tile decode GEMM against the 16-row-tile kernel's 17-21 us
+    run("dec wi   832 rows", EPI_BF16_RELU, 832, 2048, 512, st);
+    run("dec qkv  832 rows", EPI_BF16, 832, 1536, 512, st);
+    run("dec wo   832 rows", EPI_RESID, 832, 512, 2048, st);
+    run("dec o    832 rows", EPI_RESID, 832, 512, 512, st);
+    run("dec wi   256 rows", EPI_BF16_RELU, 256, 2048, 512, st);
+    run("dec wo   256 rows", EPI_RESID, 256, 512, 2048, st);
     return 0;
 }
