@@ -157,3 +157,18 @@ def test_all_gather_world_size_2_gloo(tmp_path, n):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ymt3.h is the boundary a C, Go (cgo) or Java (JNI) host would bind: it must compile as strict C99."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "ymt3.h"\nint main(void) { ymt3_config c; int (*f)(void) = ymt3_abi_version; (void)c; (void)f; return 0; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
