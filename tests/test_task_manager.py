@@ -8,7 +8,8 @@ import wave
 import numpy as np
 import pytest
 
-from yourmt3_amd.audio import load_wav, resample, slice_padded_array
+from yourmt3_amd.audio import slice_padded_array
+from host_audio import load_wav, resample
 from yourmt3_amd.config import YMT3Config
 from yourmt3_amd.midi import notes_to_midi_bytes, read_midi_notes, write_midi
 from yourmt3_amd.task_manager import (MC13_GROUPS, Note, NoteEvent, TaskManager, note_events_to_notes, DRUM_PROGRAM)

@@ -1,9 +1,9 @@
-"""Audio ingest on the host: WAV -> mono float32 -> 16 kHz -> padded fixed-length
-segments.  Uses only the stdlib `wave` reader and scipy's polyphase resampler (torchaudio/soundfile absent)."""
+"""Host side of the audio ingest: WAV file IO with the stdlib `wave` reader (torchaudio /
+soundfile absent) and synthetic test audio.  Mixing, resampling and slicing are NOT done here: they run on the device
+(`YourMT3.ingest` -> C ABI `ymt3_ingest`); `slice_padded_array` only reshapes an array that is already mono at the model rate."""
 from __future__ import annotations
 
 import wave
-from math import gcd
 from typing import Tuple
 
 import numpy as np
@@ -24,29 +24,6 @@ def load_wav_pcm(path: str) -> Tuple[np.ndarray, int]:
     else:
         raise ValueError(f"unsupported sample width {width}")
     return x.reshape(-1, nch), sr
-
-
-def load_wav(path: str) -> Tuple[np.ndarray, int]:
-    with wave.open(path, "rb") as w:
-        sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
-        raw = w.readframes(n)
-    if width == 2:
-        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-    elif width == 4:
-        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
-    elif width == 1:
-        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
-    else:
-        raise ValueError(f"unsupported sample width {width}")
-    return x.reshape(-1, nch).mean(axis=1), sr
-
-
-def resample(x: np.ndarray, sr: int, target_sr: int) -> np.ndarray:
-    if sr == target_sr:
-        return x.astype(np.float32)
-    from scipy.signal import resample_poly
-    g = gcd(sr, target_sr)
-    return resample_poly(x, target_sr // g, sr // g).astype(np.float32)
 
 
 def slice_padded_array(x: np.ndarray, slice_length: int, pad: bool = True) -> np.ndarray:
