@@ -2,7 +2,7 @@
 """Headline benchmark: audio-seconds transcribed per wall-second (RTF) on BASELINE.json configs[1]
 (MT3 base / T5-small, 2.048 s 128-mel segments, batch 64 per GPU, 1024-token greedy decode).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" is one pass of the whole hot path (audio already resident in HBM -> log-mel -> encoder ->
@@ -19,61 +19,14 @@ import statistics
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from yourmt3_amd.audio import synthetic_segments  # noqa: E402
-from yourmt3_amd.config import baseline_config  # noqa: E402
-from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens  # noqa: E402
-from yourmt3_amd.model import YourMT3  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # same guide: dense bf16 MFMA peak
 
 
-def synthetic_audio(n: int, cfg, seed: int, device) -> torch.Tensor:
-    """(n, S) fp32 synthetic segments (yourmt3_amd.audio.synthetic_segments)."""
-    return torch.from_numpy(synthetic_segments(n, cfg.segment_samples, cfg.sample_rate, seed)).to(device)
-
-
-def self_attn_algorithmic_bytes(cfg, rows: int, t: int) -> int:
-    """K and V of every (row, head), t+1 cached keys x 64 x bf16, one decoder layer."""
-    return rows * cfg.n_heads * (t + 1) * cfg.d_kv * 2 * 2
-
-
-def pmc_traffic(cfg, B: int, L: int):
-    """HBM bytes per self-attention launch from the committed rocprofv3 PMC passes (profiles/, produced by
-    scripts/gpu_pmc.sh; FETCH_SIZE doubled per the gfx950 correction).  None if the profile does not match."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_decode_attn.json")
-    if not os.path.exists(path) or B != 64 or L != 1024 or cfg.n_channels != 1:
-        return None
-    with open(path) as f:
-        return json.load(f)["self_attn"]["hbm_bytes_per_launch"]
-
-
-def cpu_baseline(cfg, sample_segments: int, sample_steps: int):
-    """The oracle (a CPU *port* of this path, there being no reference implementation) on host cores."""
-    from oracle import ymt3_oracle as O
-    from yourmt3_amd.weights import make_weights
-    W = make_weights(cfg, seed=1234)
-    a = O.synthetic_audio(sample_segments, cfg, seed=0)
-    # tiny per-step ops: more threads than ~16 only add fork/join overhead (128 threads ran 15x slower)
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    O.transcribe_segments(a, W, cfg, n_steps=sample_steps, bf16=False)
-    dt = time.perf_counter() - t0
-    # scale the audio credited by the fraction of the decode that was run (decode dominates; stated in `sample`)
-    audio_s = sample_segments * cfg.segment_seconds * (sample_steps / cfg.max_decode_len)
-    return {
-        "value": audio_s / dt, "unit": "audio_s/wall_s", "cores": cores, "kind": "port",
-        "sample": f"{sample_segments} segment(s), first {sample_steps} of {cfg.max_decode_len} decode steps, fp32 oracle, "
-                  f"{dt:.1f} s wall; audio credited pro rata to decode steps",
-    }
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -83,7 +36,130 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=32)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def synthetic_audio(n: int, cfg, seed: int, device):
+    """(n, S) fp32 synthetic segments (yourmt3_amd.audio.synthetic_segments)."""
+    import torch
+    from yourmt3_amd.audio import synthetic_segments
+    return torch.from_numpy(synthetic_segments(n, cfg.segment_samples, cfg.sample_rate, seed)).to(device)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# algorithmic bytes (SURVEY.md section 8d), all bf16
+def self_attn_bytes(cfg, rows: int, t: int) -> int:
+    """K and V of every (row, head), t+1 cached keys x 64 x bf16, one decoder layer, position t."""
+    return rows * cfg.n_heads * (t + 1) * cfg.d_kv * 2 * 2
+
+
+def cross_attn_bytes(cfg, segments: int) -> int:
+    """K and V slabs of every (segment, head), n_frames keys, one decoder layer."""
+    return segments * cfg.n_heads * cfg.n_frames * cfg.d_kv * 2 * 2
+
+
+def decoder_weight_bytes(cfg) -> dict:
+    d, inner, ff = cfg.d_model, cfg.inner, cfg.d_ff
+    per_layer = {"qkv_cache_gemm": 3 * inner * d, "self_o_gemm": d * inner, "cross_q": inner * d, "cross_o_gemm": d * inner,
+                 "ffn_wi_gemm": ff * d, "ffn_wo_gemm": d * ff}
+    out = {k: 2 * v for k, v in per_layer.items()}
+    out["lm_head_gemm"] = 2 * cfg.vocab * d
+    return out
+
+
+def decode_bytes_per_batch(cfg, segments: int, L: int) -> int:
+    """What one batch's decode must move at least once per step: every decoder weight, the cross K/V, the self K/V cache."""
+    w = decoder_weight_bytes(cfg)
+    per_step_w = sum(v for k, v in w.items() if k != "lm_head_gemm") * cfg.n_dec_layers + w["lm_head_gemm"]
+    rows = segments * cfg.n_channels
+    self_total = sum(self_attn_bytes(cfg, rows, t) for t in range(L)) * cfg.n_dec_layers
+    return L * (per_step_w + cross_attn_bytes(cfg, segments) * cfg.n_dec_layers) + self_total
+
+
+def encoder_flops_per_segment(cfg) -> float:
+    """per token per layer 4 d^2 * 2 (QKVO) + 2 d d_ff * 2 (FFN) + 4 T d (scores + AV)."""
+    T, d = cfg.n_frames, cfg.d_model
+    return float(cfg.n_enc_layers * T * (8 * d * d + 4 * d * cfg.d_ff + 4 * T * d))
+
+
+def pmc_file(name: str):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def pmc_traffic(cfg, B: int, L: int):
+    """HBM bytes per self-attention launch from the committed rocprofv3 PMC passes (profiles/, produced by
+    scripts/gpu_pmc.sh; FETCH_SIZE doubled per the gfx950 correction).  None if the profile does not match."""
+    d = pmc_file("r01_pmc_decode_attn.json")
+    if d is None or B != 64 or L != 1024 or cfg.n_channels != 1:
+        return None
+    return d["self_attn"]["hbm_bytes_per_launch"]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """The oracle (a CPU *port* of this path, there being no reference implementation) on the host cores: BASELINE
+    configs[0] (one segment) and a 16-segment batch, each on ONE thread and on all useful threads.
+    Each case runs the front-end + encoder fully and a bounded prefix of the decode; the decode time is scaled to the
+    full 1024 steps (later steps attend to more keys, so this slightly flatters the CPU)."""
+    import torch
+    from oracle import ymt3_oracle as O
+    from yourmt3_amd.config import baseline_config
+    from yourmt3_amd.weights import make_weights
+    cfg = baseline_config(0).with_(eos_id=-1)
+    W = make_weights(cfg, seed=1234)
+    n_cpu = os.cpu_count() or 1
+    # tiny per-step ops: more threads than ~16 only add fork/join overhead (128 threads ran 15x slower in round 1)
+    many = min(16, n_cpu)
+    L = cfg.max_decode_len
+    cases = [("configs[0]: 1 segment", 1, 1, 128), ("configs[0]: 1 segment", 1, many, 128),
+             ("16 segments", 16, 1, 48), ("16 segments", 16, many, 128)]
+    out = []
+    for label, B, threads, steps in cases:
+        torch.set_num_threads(threads)
+        a = O.synthetic_audio(B, cfg, seed=0)
+        t0 = time.perf_counter()
+        _, enc = O.encode(a, W, cfg, False)
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.greedy_decode(enc, W, cfg, steps, False)
+        t_dec = time.perf_counter() - t0
+        est = t_enc + t_dec * (L / steps)
+        out.append({"workload": label, "segments": B, "threads": threads, "value": B * cfg.segment_seconds / est,
+                    "encode_s": round(t_enc, 3), "decode_sample_s": round(t_dec, 3), "decode_steps_timed": steps,
+                    "ms_per_decode_step": round(1e3 * t_dec / steps, 3)})
+    torch.set_num_threads(many)
+    head = out[-1]
+    return {
+        "value": head["value"], "unit": "audio_s/wall_s", "cores": many, "kind": "port",
+        "cpu_model": cpu_model_name(), "host_logical_cpus": n_cpu,
+        "sample": f"fp32 oracle (oracle/ymt3_oracle.py), 16 segments on {many} threads: front-end + encoder in full, first "
+                  f"{head['decode_steps_timed']} of {L} decode steps timed and scaled to {L}; `variants` holds configs[0] (1 segment) "
+                  "and the 16-segment batch on 1 thread and on all useful threads",
+        "variants": out,
+    }
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def run(args):
+    import torch
+    from yourmt3_amd.config import baseline_config
+    from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens
+    from yourmt3_amd.model import YourMT3
 
     rank, world, local_rank = init_distributed(args.gpus)
     torch.cuda.set_device(local_rank)
@@ -125,12 +201,13 @@ def main():
     assert out.shape == (B * world, cfg.n_channels, L)
 
     audio_seconds = args.steps * world * B * cfg.segment_seconds
+    sec_per_batch = elapsed / args.steps
     result = {
         "metric": "audio-sec transcribed / wall-sec (RTF)",
         "value": audio_seconds / elapsed,
         "unit": "audio_s/wall_s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step": 1e3 * sec_per_batch,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "p50_segment_latency_ms": 1e3 * statistics.median(lat) / B,
@@ -145,50 +222,123 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        # dominant kernel: decoder self-attention (streams the growing KV cache).  Timed live with HIP
-        # events on the launch stream, every `stride`-th step of one eager decode of the same batch.
-        mel = model.logmel(audio)
-        enc = model.encode(mel)
-        prof = model.profile_decode(enc, L, stride=args.profile_stride)
-        sa = prof["self_attn"]
-        sampled_t = [t for t in range(L) if t % args.profile_stride == args.profile_stride // 2]
-        rows = B * cfg.n_channels
-        bytes_total = sum(self_attn_algorithmic_bytes(cfg, rows, t) for t in sampled_t) * cfg.n_dec_layers
-        assert sa["launches"] == len(sampled_t) * cfg.n_dec_layers, (sa, len(sampled_t))
-        # An event pair costs stream time of its own, so per-launch brackets over-read.  Calibrate against the true step
-        # time (one bracket around the stride-1 un-bracketed steps after every sampled step): the per-bracket overhead
-        # is (sum of all brackets of a sampled step - true step time) / launches per step.
-        span = prof["unsampled_span"]
-        kern = {k: v for k, v in prof.items() if k != "unsampled_span"}
-        n_sampled = len(sampled_t)
-        step_true_ms = span["ms_total"] / max(1, span["launches"] * (args.profile_stride - 1))
-        launches_per_step = sum(v["launches"] for v in kern.values()) / n_sampled
-        pair_ms = max(0.0, (sum(v["ms_total"] for v in kern.values()) / n_sampled - step_true_ms) / launches_per_step)
-        avg_ms = sa["ms_total"] / sa["launches"] - pair_ms
-        achieved = (bytes_total / sa["launches"]) / (avg_ms * 1e-3) / 1e9
-        result["roofline"] = {
-            "kernel": "dec_attn_kernel<true> (decoder self-attention over the KV cache)",
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(cfg, B, L),
-            "avg_launch_us": 1e3 * avg_ms, "launches_timed": sa["launches"], "event_pair_overhead_us": 1e3 * pair_ms,
-            "eager_step_us": 1e3 * step_true_ms,
-            "algorithmic_bytes_per_launch": bytes_total / sa["launches"],
-            "note": "bytes = rows*heads*(t+1)*64*2B*2 (K and V) averaged over sampled positions t = stride/2, 3*stride/2, ...; "
-                    "duration = HIP events around each sampled launch on the launch stream minus the per-bracket overhead calibrated against un-bracketed steps; traffic = FETCH_SIZE*2 + "
-                    "WRITE_SIZE per launch from profiles/r01_pmc_decode_attn.json (separate rocprofv3 --pmc passes)",
-        }
-        step_ms = {k: max(0.0, v["ms_total"] / max(1, v["launches"]) - pair_ms) * (cfg.n_dec_layers if k not in ("lm_head_gemm", "argmax_embed") else 1)
-                   for k, v in kern.items()}
-        result["decode_step_breakdown_us"] = {k: round(1e3 * v, 2) for k, v in step_ms.items()}
+        result.update(roofline_block(model, cfg, audio, B, L, args.profile_stride, sec_per_batch))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(baseline_config(0).with_(eos_id=-1), sample_segments=16, sample_steps=1024)
+        result["cpu_baseline"] = cpu_baseline()
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     model.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def roofline_block(model, cfg, audio, B, L, stride, sec_per_batch) -> dict:
+    """Live per-kernel-class timing of one eager decode of the same batch (HIP events on the launch stream, every
+    `stride`-th position, calibrated against un-bracketed steps), priced against the gfx950 peaks."""
+    import torch
+    out = {}
+    mel = model.logmel(audio)
+    # encoder: MFMA-bound (SURVEY 8d).  Timed live with events around ymt3_encode on the launch stream.
+    enc = model.encode(mel)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        enc = model.encode(mel)
+    e1.record()
+    torch.cuda.synchronize()
+    enc_ms = e0.elapsed_time(e1) / reps
+    enc_tflops = encoder_flops_per_segment(cfg) * B / (enc_ms * 1e-3) / 1e12
+    gm = pmc_file("r01_pmc_gemm_mfma.json")
+    out["mfma_util"] = {
+        "encoder_whole": enc_tflops / MFMA_BF16_PEAK_TFLOPS, "encoder_tflops": enc_tflops, "encoder_ms": enc_ms,
+        "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
+        "gemm_pmc": None if gm is None else {k.split(" (")[0]: v["mfma_utilisation"] for k, v in gm["kernels"].items()},
+        "note": "encoder_whole = 10.47 GFLOP x segments / live time of ymt3_encode (front-end excluded; norms, attention and "
+                "epilogues included) / 2.5 PFLOP/s dense bf16; gemm_pmc = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE) "
+                "per GEMM kernel from profiles/r01_pmc_gemm_mfma.json (separate rocprofv3 --pmc passes)",
+    }
+
+    prof = model.profile_decode(enc, L, stride=stride)
+    sampled_t = [t for t in range(L) if t % stride == stride // 2]
+    rows = B * cfg.n_channels
+    n_sampled = len(sampled_t)
+    span = prof["unsampled_span"]
+    kern = {k: v for k, v in prof.items() if k != "unsampled_span" and v["launches"] > 0}
+    # An event pair costs stream time of its own, so per-launch brackets over-read.  Calibrate against the true step
+    # time (one bracket around the stride-1 un-bracketed steps after every sampled step): the per-bracket overhead
+    # is (sum of all brackets of a sampled step - true step time) / launches per step.
+    step_true_ms = span["ms_total"] / max(1, span["launches"] * (stride - 1))
+    launches_per_step = sum(v["launches"] for v in kern.values()) / n_sampled
+    pair_ms = max(0.0, (sum(v["ms_total"] for v in kern.values()) / n_sampled - step_true_ms) / launches_per_step)
+    us = {k: 1e3 * max(0.0, v["ms_total"] / v["launches"] - pair_ms) for k, v in kern.items()}       # per launch
+    per_step = {k: v["launches"] / n_sampled for k, v in kern.items()}                                 # launches per step
+    step_us = sum(us[k] * per_step[k] for k in kern)
+
+    sa_bytes = sum(self_attn_bytes(cfg, rows, t) for t in sampled_t) / n_sampled
+    assert kern["self_attn"]["launches"] == n_sampled * cfg.n_dec_layers, (kern["self_attn"], n_sampled)
+    ca_bytes = cross_attn_bytes(cfg, B)
+    wb = decoder_weight_bytes(cfg)
+
+    def hbm(bytes_per_launch, name):
+        gbs = bytes_per_launch / (us[name] * 1e-6) / 1e9
+        return {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_us": us[name], "algorithmic_bytes_per_launch": bytes_per_launch,
+                "share_of_step": us[name] * per_step[name] / step_us}
+
+    sa = hbm(sa_bytes, "self_attn")
+    shares = {k: us[k] * per_step[k] / step_us for k in kern}
+    top = max(shares, key=shares.get)
+    out["roofline"] = {
+        "kernel": "dec_attn_kernel<true> (decoder self-attention over the KV cache)" if top == "self_attn" else top,
+        "bound": "hbm", "achieved": sa["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sa["frac"],
+        "traffic": pmc_traffic(cfg, B, L),
+        "avg_launch_us": sa["avg_launch_us"], "launches_timed": kern["self_attn"]["launches"], "event_pair_overhead_us": 1e3 * pair_ms,
+        "eager_step_us": 1e3 * step_true_ms, "share_of_step": sa["share_of_step"],
+        "algorithmic_bytes_per_launch": sa_bytes,
+        "note": "top kernel by aggregate share of the decode step; bytes = rows*heads*(t+1)*64*2B*2 (K and V) averaged over sampled positions "
+                "t = stride/2, 3*stride/2, ...; duration = HIP events around each sampled launch on the launch stream minus the per-bracket "
+                "overhead calibrated against un-bracketed steps; traffic = FETCH_SIZE*2 + WRITE_SIZE per launch from "
+                "profiles/r01_pmc_decode_attn.json (separate rocprofv3 --pmc passes)",
+    }
+    total_bytes = decode_bytes_per_batch(cfg, B, L)
+    path_gbs = total_bytes / sec_per_batch / 1e9
+    out["roofline_path"] = {
+        "bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": path_gbs / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_batch": total_bytes,
+        "note": "whole hot path: (decoder weights + cross K/V per step + self K/V cache at each position, summed over the decode) / "
+                "measured seconds per batch (graph replay, the timed region above); front-end and encoder (MFMA-bound, < 1 % of a batch) add no bytes here",
+    }
+    gemm_names = [k for k in kern if k.endswith("_gemm")]
+    gemm_us = sum(us[k] * per_step[k] for k in gemm_names)
+    gemm_bytes = sum(wb.get(k, 0) * per_step[k] for k in gemm_names)
+    out["roofline_kernels"] = {
+        "cross_attn": hbm(ca_bytes + (wb["cross_q"] if "cross_q_gemm" not in kern else 0), "cross_attn") if "cross_attn" in kern else None,
+        "dec_gemm_family": {"share_of_step": gemm_us / step_us, "launches_per_step": sum(per_step[k] for k in gemm_names),
+                            "weight_bytes_per_step": gemm_bytes, "achieved": gemm_bytes / (gemm_us * 1e-6) / 1e9,
+                            "frac": gemm_bytes / (gemm_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                            "note": "latency-bound skinny GEMMs (64 rows): weight bytes / time, against the HBM peak"},
+        "launches_per_step": launches_per_step,
+    }
+    out["decode_step_breakdown_us"] = {k: round(us[k] * per_step[k], 2) for k in kern}
+    return out
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  The parent never touches the GPU (no HIP call before or
+        # after this point); every rank is a fresh child process with RANK / LOCAL_RANK / WORLD_SIZE set.
+        from yourmt3_amd.dist import launch_local_ranks
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+        sys.exit(launch_local_ranks(args.gpus, cmd))
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
+                 f"(python bench.py --gpus N starts them itself)")
+    run(args)
 
 
 if __name__ == "__main__":

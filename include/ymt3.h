@@ -129,11 +129,12 @@ int ymt3_debug_step_stamps(ymt3_handle h, int32_t* cls, int32_t* grid, uint64_t*
 /* The raw (entry, exit) pairs of kernel `kernel` of the step, one per workgroup in blockIdx order (capacity in workgroups). */
 int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* stamps, int capacity_wgs);
 
-/* Measurement hook: later decode calls start at cache position `step0` instead of 0 (the cache below
- * it holds whatever earlier calls left, so the TOKENS are meaningless; the memory traffic of positions
- * step0.. is exactly that of a real decode).  Lets a profiler cover late positions in a short run:
- * rocprofv3 7.2 --pmc segfaults beyond ~30k dispatches per process.  0 restores normal decoding. */
-int ymt3_set_profile_start(ymt3_handle h, int step0);
+/* Debug hook, NOT part of the product surface: refused (YMT3_ERR_UNSUPPORTED) unless the handle was created with
+ * YMT3_DEBUG_HOOKS=1 in the environment.  The NEXT ymt3_decode_greedy / ymt3_transcribe_segments call -- that one call
+ * only -- starts at cache position `step0` instead of 0; cache positions [0, step0) are zero-filled here, so the call
+ * reads defined memory, but its TOKENS are meaningless.  The memory traffic of positions step0.. is exactly that of a
+ * real decode, which lets a counter pass (rocprofv3 --pmc) cover late positions with a short process. */
+int ymt3_debug_decode_start(ymt3_handle h, int step0);
 
 /* Unit-test hooks: C = A(bf16 MxK) * W^T(bf16 NxK), f32 out; runs the encoder GEMM kernel. */
 int ymt3_test_gemm(ymt3_handle h, const void* a_dev, const void* w_dev, float* c_dev, int M, int N, int K, void* stream);

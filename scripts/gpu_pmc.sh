@@ -2,8 +2,10 @@
 # HBM traffic counters for the decode attention kernels: one counter per pass, kernel-trace only (as
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Uses the torch-free C host (tools/ymt3_run), restricts
 # collection to the attention kernels and covers the 1024 positions as four 256-step pieces
-# (ymt3_set_profile_start): rocprofv3 7.2 --pmc segfaults on longer runs (it is flaky even at 512 steps).
+# (debug hook ymt3_debug_decode_start, accepted under YMT3_DEBUG_HOOKS=1): rocprofv3 7.2 --pmc aborts on longer runs, see
+# profiles/r02_notes.md for the attribution.
 export TMPDIR=/tmp
+export YMT3_DEBUG_HOOKS=1
 mkdir -p gpurun_out
 python3 -m yourmt3_amd.export_blob /tmp/blob.bin 1 || exit 1
 for ctr in FETCH_SIZE WRITE_SIZE; do

@@ -137,7 +137,7 @@ _WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, sys.argv[1])
 from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens
-rank, world, _ = init_distributed()
+rank, world, _ = init_distributed(int(os.environ["WORLD_SIZE"]))
 n = int(sys.argv[2])
 lo, hi = shard_range(n, rank, world)
 full = (torch.arange(n * 3 * 5, dtype=torch.int32).view(n, 3, 5) * 7) % 1000
@@ -157,6 +157,40 @@ def test_all_gather_world_size_2_gloo(tmp_path, n):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_launcher_starts_one_rank_per_gpu_and_gathers(tmp_path):
+    """`python bench.py --gpus N` without WORLD_SIZE becomes the launcher (yourmt3_amd.dist.launch_local_ranks): N fresh
+    children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set.  Here the children are the gloo worker above."""
+    from yourmt3_amd.dist import launch_local_ranks
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    code = ("import sys; sys.path.insert(0, %r); from yourmt3_amd.dist import launch_local_ranks; "
+            "sys.exit(launch_local_ranks(2, [sys.executable, %r, %r, '7'], timeout=170))" % (ROOT, str(script), ROOT))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(l for l in r.stdout.splitlines() if l.startswith("rank")) == ["rank 0 ok", "rank 1 ok"]
+    # a failing rank ends the job with its exit code instead of leaving the others in a collective
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(60)\n")
+    t0 = __import__("time").time()
+    assert launch_local_ranks(2, [sys.executable, str(bad)], timeout=50) == 3
+    assert __import__("time").time() - t0 < 30
+
+
+def test_bench_refuses_a_rank_count_mismatch_and_never_runs_without_a_gpu():
+    """No silent 1-rank run when N ranks were asked for; and with no GPU the ranks fail loudly (no CPU fallback)."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        env.pop("WORLD_SIZE", None)
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=dict(env, YMT3_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "GPU" in (r.stdout + r.stderr) and '"metric"' not in r.stdout
 
 
 def test_header_is_plain_c(tmp_path):

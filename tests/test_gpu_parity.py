@@ -473,16 +473,32 @@ def test_profile_hooks(small):
     prof = small.profile_decode(e, 32, stride=8)
     assert prof["self_attn"]["launches"] == 4 * SMALL.n_dec_layers and prof["self_attn"]["ms_total"] > 0
     assert prof["lm_head_gemm"]["launches"] == 4 and prof["unsampled_span"]["launches"] == 3
-    ref = small.decode(e, 16).cpu()
+
+
+def test_decode_start_debug_hook_is_gated_and_one_shot(small, monkeypatch):
+    """ymt3_debug_decode_start (late cache positions for short counter passes) is not product surface: a normal handle
+    refuses it; under YMT3_DEBUG_HOOKS=1 it applies to ONE decode call, which reads zero-filled positions below step0."""
     from yourmt3_amd import _lib
-    _lib.check(small._lib.ymt3_set_profile_start(small._handle, 8))
-    try:
-        with pytest.raises(_lib.YMT3Error):
-            small.decode(e, SMALL.max_decode_len)              # 8 + 64 > max_decode_len
-        assert small.decode(e, 16).shape == (2, 1, 16)         # runs from position 8; ids are not meaningful
-    finally:
-        _lib.check(small._lib.ymt3_set_profile_start(small._handle, 0))
+    e = small.encode(small.logmel(O.synthetic_audio(2, SMALL).cuda()))
+    ref = small.decode(e, 16).cpu()
+    assert small._lib.ymt3_debug_decode_start(small._handle, 8) == 4                       # YMT3_ERR_UNSUPPORTED
     assert torch.equal(small.decode(e, 16).cpu(), ref)
+    monkeypatch.setenv("YMT3_DEBUG_HOOKS", "1")
+    m = _model(SMALL)
+    monkeypatch.delenv("YMT3_DEBUG_HOOKS")
+    _lib.check(m._lib.ymt3_debug_decode_start(m._handle, 8))
+    with pytest.raises(_lib.YMT3Error):
+        m.decode(e, SMALL.max_decode_len)                      # 8 + 64 > max_decode_len; the hook is consumed by this call
+    assert torch.equal(m.decode(e, 16).cpu(), ref)             # back to position 0 without being told
+    _lib.check(m._lib.ymt3_debug_decode_start(m._handle, 8))
+    late = m.decode(e, 16)                                     # runs from position 8 over zero keys; ids are not meaningful
+    assert late.shape == (2, 1, 16) and torch.equal(m.decode(e, 16).cpu(), ref)
+    _lib.check(m._lib.ymt3_debug_decode_start(m._handle, 8))
+    assert torch.equal(m.decode(e, 16), late)                  # defined memory below step0: reproducible
+    _lib.check(m._lib.ymt3_debug_decode_start(m._handle, 8))
+    with pytest.raises(_lib.YMT3Error):
+        m.inference_stream(O.synthetic_audio(2, SMALL).cuda(), max_token_length=8)
+    m.close()
 
 
 def test_step_stamps_hook(small, monkeypatch):

@@ -152,6 +152,53 @@ def test_midi_roundtrip(tmp_path):
     assert open(p, "rb").read() == data
 
 
+def _channel_programs(data):
+    """{channel: set of programs} and {channel: note-on count} of a file written by notes_to_midi_bytes"""
+    import struct
+    progs, ons, pos = {}, {}, 14
+    ntrk = struct.unpack(">H", data[10:12])[0]
+    for _ in range(ntrk):
+        ln = struct.unpack(">I", data[pos + 4:pos + 8])[0]
+        p, end = pos + 8, pos + 8 + ln
+        while p < end:
+            while data[p] & 0x80:
+                p += 1
+            p += 1
+            st = data[p]; p += 1
+            if st == 0xFF:
+                p += 2 + data[p + 1]
+            elif st & 0xF0 == 0xC0:
+                progs.setdefault(st & 15, set()).add(data[p]); p += 1
+            else:
+                if st & 0xF0 == 0x90:
+                    ons[st & 15] = ons.get(st & 15, 0) + 1
+                p += 2
+        pos = end
+    return progs, ons
+
+
+def test_more_programs_than_midi_channels_merge_by_family_never_alias():
+    """22 melodic programs + drums + singing: 15 melodic channels, exactly one program each; programs of one GM family share
+    the family's lowest program; no note is lost; the singing voice (program 129) is written as GM 53."""
+    from yourmt3_amd.midi import gm_program
+    progs = [0, 1, 2, 3, 8, 9, 16, 17, 24, 25, 26, 32, 33, 40, 41, 48, 56, 64, 72, 80, 88, 96]
+    notes = [Note(0.1 * i, 0.1 * i + 0.05, False, p, 40 + i) for i, p in enumerate(progs)]
+    notes += [Note(0.2, 0.3, False, 129, 70), Note(0.5, 0.51, True, DRUM_PROGRAM, 36)]
+    data = notes_to_midi_bytes(notes)
+    by_ch, ons = _channel_programs(data)
+    assert 9 not in by_ch and len(by_ch) <= 15 and all(len(v) == 1 for v in by_ch.values())
+    assert sum(ons.values()) == len(notes) and ons[9] == 1
+    written = {next(iter(v)) for v in by_ch.values()}
+    assert gm_program(129) == 53 and 53 in written
+    assert {0, 24} <= written and not ({1, 2, 3, 25, 26} & written)           # the largest families were folded first
+    assert notes_to_midi_bytes(notes) == data                                   # deterministic
+    few = [Note(0.0, 0.1, False, p, 60) for p in range(15)] + [Note(0.0, 0.1, False, 129, 61)]
+    by_ch, _ = _channel_programs(notes_to_midi_bytes(few[:15]))
+    assert sorted(next(iter(v)) for v in by_ch.values()) == list(range(15))   # 15 programs: untouched, one channel each
+    with pytest.raises(ValueError):
+        gm_program(130)
+
+
 def test_slice_padded_array_and_wav_ingest(tmp_path):
     x = np.arange(70000, dtype=np.float32)
     s = slice_padded_array(x, 32767)

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
 
     ymt3_handle h = nullptr;
     if (ymt3_create(&cfg, blob.data(), n, 0, &h) != YMT3_OK) { fprintf(stderr, "create: %s\n", ymt3_last_error()); return 1; }
-    if (step0 && ymt3_set_profile_start(h, step0) != YMT3_OK) { fprintf(stderr, "%s\n", ymt3_last_error()); return 1; }
+    if (step0 && ymt3_debug_decode_start(h, step0) != YMT3_OK)   /* needs YMT3_DEBUG_HOOKS=1; applies to the first pass only */ { fprintf(stderr, "%s\n", ymt3_last_error()); return 1; }
     std::vector<float> audio((size_t)B * cfg.segment_samples);
     unsigned s = 12345u;
     for (size_t i = 0; i < audio.size(); ++i) {

@@ -65,7 +65,7 @@ struct DecodeShared {           // device-resident loop state, read by every dec
     int step;                   // position being decoded (tokens already in the cache)
     int done_count;             // ticket counter of the argmax kernel
     int n_steps;                // row stride of tokens_out / forced / logits_out
-    int step0;                  // first position of this call (0 except under ymt3_set_profile_start)
+    int step0;                  // first position of this call (0 except under the debug hook ymt3_debug_decode_start)
     int n_unfinished;           // rows of this chain that have not emitted EOS yet (maintained when eos_id >= 0)
     int pad1;
     int32_t* tokens_out;        // [R][n_steps]

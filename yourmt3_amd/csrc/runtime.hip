@@ -12,7 +12,9 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ymt3.h"
@@ -87,6 +89,7 @@ struct ymt3_ctx {
     // it loses -- every hipGraphLaunch of the ~50-node step costs ~150 us of host time, so 2/4/8 chains
     // ran 372/653/937 ms per batch against 351 ms for one chain.  Default 1; YMT3_CHAINS overrides.
     int n_chains = 1;
+    bool chain_threads = true;              // one launcher thread per chain (YMT3_CHAIN_THREADS=0: the caller's thread feeds all)
     hipStream_t chain_stream[8] = {};
     hipEvent_t fork_ev = nullptr, join_ev[8] = {};
     std::map<long, StepGraph> step_graphs;  // keyed by (B, n_chains_used, chain)
@@ -98,7 +101,8 @@ struct ymt3_ctx {
     bool prof_span_open = false;
     int early_stop_interval = 0;            // ymt3_set_early_stop: host checks `n_unfinished` every N steps (0 = never)
     int* host_flag = nullptr;               // pinned, for that check
-    int prof_step0 = 0;                     // ymt3_set_profile_start: decode positions begin here (measurement only)
+    bool debug_hooks = false;               // YMT3_DEBUG_HOOKS=1 at create: ymt3_debug_decode_start is accepted
+    int prof_step0 = 0;                     // ymt3_debug_decode_start: the next decode call begins at this position (one shot)
     std::vector<hipEvent_t> prof_ev;        // pairs
     std::vector<int> prof_cls;
     // measurement (YMT3_STAMP=1): per-workgroup wall-clock stamps of the decode-step kernels, slot = launch order in the step
@@ -323,12 +327,16 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
         HIP_TRY(hipMemset(c->stamp_buf, 0, (size_t)STAMP_NODES * STAMP_WGS * 2 * sizeof(unsigned long long)));
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    const char* dh = getenv("YMT3_DEBUG_HOOKS");
+    c->debug_hooks = dh && dh[0] == '1';
     const char* ng = getenv("YMT3_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     const char* nf = getenv("YMT3_NO_FUSEQ");
     c->fuse_q = !(nf && nf[0] == '1');
     const char* nc = getenv("YMT3_CHAINS");
     if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
+    const char* ct = getenv("YMT3_CHAIN_THREADS");
+    c->chain_threads = !(ct && ct[0] == '0');
     for (int i = 0; i < c->n_chains; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&c->chain_stream[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
@@ -582,7 +590,9 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
 static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int32_t* tokens, const int32_t* forced,
                        float* logits_out, hipStream_t s, int prof_stride = 0) {
     const ymt3_config& k = h->cfg;
-    if (n_steps <= 0 || h->prof_step0 + n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len - h->prof_step0);
+    const int step0 = h->prof_step0;          // one shot (debug hook): consumed by this call whatever its outcome
+    h->prof_step0 = 0;
+    if (n_steps <= 0 || step0 + n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len - step0);
     const int d = k.d_model, R = B * k.n_channels;
     // a6: cross-attention K/V of every decoder layer in one GEMM, stored as per-(segment, head) slabs
     GemmArgs g{enc, h->wkv_all, h->ckv, nullptr, B * h->T, k.n_dec_layers * 2 * h->inner, d, d, d, 0, h->T, k.n_heads, B};
@@ -596,7 +606,7 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
     // chains: contiguous, near-equal row ranges
     int n_chains = (!h->use_graph || prof_stride > 0 || k.dec_ffn == YMT3_FFN_MOE) ? 1 : h->n_chains;   // MoE pair tables are per handle
     if (n_chains > R) n_chains = R;
-    LAUNCH(launch_decode_init(a, n_chains, n_steps, h->prof_step0, tokens, forced, logits_out, s));
+    LAUNCH(launch_decode_init(a, n_chains, n_steps, step0, tokens, forced, logits_out, s));
     int row0[9];
     row0[0] = 0;
     for (int c = 0; c < n_chains; ++c) row0[c + 1] = row0[c] + R / n_chains + (c < R % n_chains ? 1 : 0);
@@ -663,8 +673,25 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
             // fork: every chain stream waits for the cross-KV GEMM + init on the caller's stream
             HIP_TRY(hipEventRecord(h->fork_ev, s));
             for (int c = 0; c < n_chains; ++c) HIP_TRY(hipStreamWaitEvent(h->chain_stream[c], h->fork_ev, 0));
-            for (int t = 0; t < n_steps; ++t)
-                for (int c = 0; c < n_chains; ++c) HIP_TRY(hipGraphLaunch(exec[c], h->chain_stream[c]));
+            if (h->chain_threads) {
+                // one host thread per chain: a hipGraphLaunch of the ~44-node step costs the host 60-150 us, so ONE thread
+                // feeding n chains is host-bound as soon as a chain's step is shorter than n launches
+                std::atomic<int> bad{0};
+                std::vector<std::thread> th;
+                for (int c = 1; c < n_chains; ++c)
+                    th.emplace_back([&, c] {
+                        if (hipSetDevice(h->device) != hipSuccess) { bad = 1; return; }
+                        for (int t = 0; t < n_steps && !bad; ++t)
+                            if (hipGraphLaunch(exec[c], h->chain_stream[c]) != hipSuccess) bad = 1;
+                    });
+                for (int t = 0; t < n_steps && !bad; ++t)
+                    if (hipGraphLaunch(exec[0], h->chain_stream[0]) != hipSuccess) bad = 1;
+                for (auto& t : th) t.join();
+                if (bad) FAIL(YMT3_ERR_HIP, "hipGraphLaunch failed on a decode chain: %s", hipGetErrorString(hipGetLastError()));
+            } else {
+                for (int t = 0; t < n_steps; ++t)
+                    for (int c = 0; c < n_chains; ++c) HIP_TRY(hipGraphLaunch(exec[c], h->chain_stream[c]));
+            }
             // join: the caller's stream continues only after every chain has emitted its last token
             for (int c = 0; c < n_chains; ++c) {
                 HIP_TRY(hipEventRecord(h->join_ev[c], h->chain_stream[c]));
@@ -713,6 +740,7 @@ extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int
     const ymt3_config& k = h->cfg;
     if (n_steps <= 0 || n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len);
     if (interval < 0) FAIL(YMT3_ERR_ARG, "interval=%d", interval);
+    if (h->prof_step0) FAIL(YMT3_ERR_UNSUPPORTED, "ymt3_debug_decode_start is pending: it applies to lock-step decode calls only");
     if (interval == 0) interval = 8;
     if (slots <= 0 || slots > h->maxB) slots = h->maxB;
     if (slots > n_segments) slots = n_segments;
@@ -872,9 +900,19 @@ extern "C" int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* sta
     return YMT3_OK;
 }
 
-extern "C" int ymt3_set_profile_start(ymt3_handle h, int step0) {
+extern "C" int ymt3_debug_decode_start(ymt3_handle h, int step0) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (!h->debug_hooks) FAIL(YMT3_ERR_UNSUPPORTED, "debug hooks are accepted only by a handle created with YMT3_DEBUG_HOOKS=1 in the environment");
     if (step0 < 0 || step0 >= h->cfg.max_decode_len) FAIL(YMT3_ERR_ARG, "step0=%d outside [0, %d)", step0, h->cfg.max_decode_len);
+    HIP_TRY(hipSetDevice(h->device));
+    if (step0 > 0) {
+        // positions [0, step0) of every (layer, row, head) slab: defined (zero) keys and values instead of whatever hipMalloc left
+        const ymt3_config& k = h->cfg;
+        const size_t slabs = (size_t)k.n_dec_layers * h->maxR * k.n_heads, pitch = (size_t)k.max_decode_len * 64 * sizeof(bf16_t);
+        HIP_TRY(hipMemset2D(h->kcache, pitch, 0, (size_t)step0 * 64 * sizeof(bf16_t), slabs));
+        HIP_TRY(hipMemset2D(h->vcache, pitch, 0, (size_t)step0 * 64 * sizeof(bf16_t), slabs));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     h->prof_step0 = step0;
     return YMT3_OK;
 }

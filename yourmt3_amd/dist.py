@@ -6,15 +6,75 @@ Works on CPU with gloo for the world_size-2 tests.
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+import socket
+import subprocess
+import sys
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-def init_distributed(n_gpus_hint: int = 1) -> Tuple[int, int, int]:
-    """Read RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run) and join the process group."""
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_local_ranks(n_ranks: int, cmd: Sequence[str], extra_env: Optional[Dict[str, str]] = None,
+                       timeout: Optional[float] = None) -> int:
+    """Start `n_ranks` fresh child processes of `cmd` on this node, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT set (what torch.distributed.run would set), wait for all of them and return the
+    first non-zero exit code (0 if every rank succeeded).  The caller must not have initialised HIP: children are new
+    processes (never an exec of a process that touched the GPU), and they inherit stdout, so rank 0's one JSON line is
+    the launcher's output.  When a rank fails, the others are terminated by PID (they would otherwise wait in a
+    collective for ever)."""
+    if n_ranks < 1:
+        raise ValueError("n_ranks must be >= 1")
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(cmd), env=env))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or (deadline is not None and time.monotonic() > deadline):
+            if rc == 0:
+                rc = 124
+                print(f"launch_local_ranks: timeout after {timeout} s", file=sys.stderr)
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def init_distributed(n_gpus: int = 1) -> Tuple[int, int, int]:
+    """Read RANK / WORLD_SIZE / LOCAL_RANK (set by torch.distributed.run or launch_local_ranks) and join the process
+    group.  `n_gpus` is what the caller asked for: a mismatch with WORLD_SIZE is an error, never a silent 1-rank run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n_gpus != world:
+        raise RuntimeError(f"asked for {n_gpus} ranks but WORLD_SIZE={world}: start one process per GPU "
+                           "(yourmt3_amd.dist.launch_local_ranks or torch.distributed.run)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():

@@ -23,14 +23,59 @@ def _ticks(sec: float) -> int:
     return int(round(sec * TICKS_PER_BEAT * 1e6 / TEMPO_US))
 
 
+SINGING_PROGRAM = 129
+SINGING_GM_PROGRAM = 53                # GM "Voice Oohs": the defined stand-in for the vocabulary's singing-voice program
+
+
+def gm_program(program: int) -> int:
+    """Vocabulary program -> General MIDI program number of the program-change event."""
+    if program == SINGING_PROGRAM:
+        return SINGING_GM_PROGRAM
+    if not 0 <= program <= 127:
+        raise ValueError(f"program {program} has no General MIDI number")
+    return program
+
+
+def _fit_melodic_channels(by_prog: Dict[int, List[Note]]) -> Dict[int, List[Note]]:
+    """A Standard MIDI File has 15 melodic channels (16 minus the drum channel) and ONE program per channel at a time.
+    With more than 15 melodic programs, programs of one GM instrument family (program // 8) are merged onto the family's
+    lowest program present, largest families first, until 15 remain -- deterministic, and never two programs on one
+    channel.  Still more than 15 distinct families (only with all 16 GM families plus singing present): error."""
+    melodic = sorted(p for p in by_prog if p != DRUM_PROGRAM)
+    if len(melodic) <= 15:
+        return by_prog
+    family = lambda p: 16 if p == SINGING_PROGRAM else p // 8
+    groups: Dict[int, List[int]] = {}
+    for p in melodic:
+        groups.setdefault(family(p), []).append(p)
+    merged = {p: p for p in melodic}
+    n = len(melodic)
+    for fam in sorted(groups, key=lambda f: (-len(groups[f]), f)):
+        if n <= 15:
+            break
+        members = groups[fam]
+        if len(members) > 1:
+            for p in members[1:]:
+                merged[p] = members[0]
+            n -= len(members) - 1
+    if n > 15:
+        raise ValueError(f"{n} instrument families do not fit the 15 melodic MIDI channels")
+    out: Dict[int, List[Note]] = {}
+    for p, ns in by_prog.items():
+        out.setdefault(merged.get(p, p), []).extend(ns)
+    return out
+
+
 def notes_to_midi_bytes(notes: Sequence[Note]) -> bytes:
     by_prog: Dict[int, List[Note]] = {}
     for n in notes:
         by_prog.setdefault(DRUM_PROGRAM if n.is_drum else n.program, []).append(n)
     tracks = [b"\x00\xff\x51\x03" + TEMPO_US.to_bytes(3, "big") + b"\x00\xff\x2f\x00"]
+    by_prog = _fit_melodic_channels(by_prog)
     melodic_channels = [c for c in range(16) if c != 9]
-    for i, (prog, ns) in enumerate(sorted(by_prog.items())):
-        ch = 9 if prog == DRUM_PROGRAM else melodic_channels[i % 15]
+    melodic = [p for p in sorted(by_prog) if p != DRUM_PROGRAM]
+    for prog, ns in sorted(by_prog.items()):
+        ch = 9 if prog == DRUM_PROGRAM else melodic_channels[melodic.index(prog)]
         ev = []
         # one voice per (channel, pitch): a note still sounding when the same pitch starts again ends at that onset, and a
         # second note starting on the same tick is dropped -- otherwise the note-ons and note-offs of the file do not pair up
@@ -51,7 +96,7 @@ def notes_to_midi_bytes(notes: Sequence[Note]) -> bytes:
         ev.sort(key=lambda e: (e[0], e[1]))            # offsets before onsets at the same tick
         body = bytearray()
         if prog != DRUM_PROGRAM:
-            body += b"\x00" + bytes([0xC0 | ch, min(prog, 127)])
+            body += b"\x00" + bytes([0xC0 | ch, gm_program(prog)])
         last = 0
         for tick, on, pitch, vel in ev:
             body += _vlq(tick - last) + bytes([(0x90 if on else 0x80) | ch, pitch & 0x7F, vel & 0x7F])

@@ -37,8 +37,8 @@ class YourMT3:
         blob = pack_blob({**self.weights, **derived_tables(self.weights, cfg)})
         self._handle = ctypes.c_void_p()
         ccfg = to_c(cfg, self.max_batch)
-        buf = ctypes.create_string_buffer(blob, len(blob))
-        _lib.check(self._lib.ymt3_create(ctypes.byref(ccfg), buf, len(blob), device, ctypes.byref(self._handle)))
+        # `blob` is immutable bytes: c_char_p points at its buffer (no second ~91 MB host copy); ymt3_create only reads it
+        _lib.check(self._lib.ymt3_create(ctypes.byref(ccfg), ctypes.c_char_p(blob), len(blob), device, ctypes.byref(self._handle)))
 
     def close(self):
         if getattr(self, "_handle", None) and self._handle.value:

@@ -6,7 +6,7 @@ Pure integer / float64 host work, done once per (config, checkpoint):
 
 The bucket function restates TP: transformers/models/t5/modeling_t5.py:216-262 (fp32 log, truncation
 toward zero) so that boundaries (e.g. |rel| = 16, 32, 64, 128) land in the same bucket as HF T5;
-tests/test_tables.py checks it bit-exactly against that code and against the oracle.
+tests/test_cpu_host.py::test_bucket_tables_match_oracle_hf_and_golden checks it bit-exactly against that code and against the oracle.
 """
 from __future__ import annotations
 
