@@ -110,6 +110,10 @@ int ymt3_transcribe_segments(ymt3_handle h, const float* audio_dev, int B, int n
 int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int n_segments, int n_steps, int32_t* tokens_dev,
                            int slots, int interval, void* stream);
 
+/* Number of decoder steps the last decode call on this handle actually launched (ymt3_decode_greedy,
+ * ymt3_transcribe_segments: n_steps unless ymt3_set_early_stop cut it short; ymt3_transcribe_stream: every step of every round). */
+int ymt3_last_decode_steps(ymt3_handle h);
+
 /* Measurement hook (bench.py `roofline`): decode eagerly (no graph) and bracket every kernel launch of
  * every `stride`-th step (positions stride/2, 3*stride/2, ...) with HIP events on `stream`; synchronises the stream before returning.
  * Classes: 0 qkv+cache GEMM, 1 self-attention, 2 self O-proj, 3 cross Q GEMM, 4 cross-attention,

@@ -4,9 +4,14 @@ Tolerances (the numerics contract of DESIGN.md: bf16 GEMM operands, fp32 accumul
   log-mel           abs 1e-3 on natural-log values (fp32 FFT vs pocketfft, sparse vs dense mel sum)
   encoder output    bf16 values of unit RMS: max abs 0.0625 (a few bf16 ulps), mean abs 4e-3
   logits            unit std fp32: max abs 0.06, mean abs 6e-3
-  token ids         BIT EXACT wherever the oracle's top-2 logit margin exceeds TAU = 0.06 (the logits
-                    tolerance); a free-running stream must be identical up to its first sub-TAU step.
+  token ids         BIT EXACT wherever the oracle's top-2 logit margin exceeds TAU = 0.03 (a little over 2x the measured
+                    max logit error of 0.013: an argmax can only move if the two errors sum to more than the margin);
+                    a free-running stream must be identical up to its first sub-TAU step.  Every id check records the
+                    fraction of steps it covered and how many sub-TAU steps differed (gpurun_out/r02_parity_report.json);
+                    at least MIN_SAFE of the steps must be covered.
 """
+import atexit
+import json
 import os
 
 import numpy as np
@@ -18,7 +23,9 @@ from yourmt3_amd.config import YMT3Config
 from yourmt3_amd.weights import make_weights, bf16_bits_to_f32
 
 pytestmark = pytest.mark.gpu
-TAU = 0.06
+TAU = 0.03
+MIN_SAFE = 0.8
+_REPORT = {}
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 SMALL = YMT3Config(segment_samples=8191, max_decode_len=64)
@@ -43,6 +50,42 @@ def full():
     m = _model(FULL)
     yield m
     m.close()
+
+
+def _dump_report():
+    if _REPORT:
+        try:
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(os.path.join("gpurun_out", "r02_parity_report.json"), "w") as f:
+                json.dump(_REPORT, f, indent=1)
+        except OSError:
+            pass
+
+
+atexit.register(_dump_report)
+
+
+def _check_ids(name, got_t, ref_t, ref_l, got_l=None, tau=TAU, stable=None, tol_max=0.06, tol_mean=6e-3, min_safe=MIN_SAFE):
+    """Teacher-forced ids against the oracle: equal wherever the oracle's margin >= tau (and `stable`), with the share
+    of steps that covers, the number of uncovered steps that differ, and the logits errors, recorded and bounded."""
+    got_t, ref_t = got_t.cpu(), ref_t.cpu()
+    safe = _margin(ref_l) >= tau
+    if stable is not None:
+        safe = safe & stable
+    rec = {"tau": tau, "steps": int(safe.numel()), "safe_fraction": float(safe.float().mean()),
+           "ids_differ_where_safe": int((got_t[safe] != ref_t[safe]).sum()),
+           "ids_differ_below_tau": int((got_t[~safe] != ref_t[~safe]).sum())}
+    if got_l is not None:
+        d = (got_l.cpu() - ref_l).abs()
+        rec["logits_max_abs"] = float(d.amax(-1)[stable].max()) if stable is not None else float(d.max())
+        rec["logits_mean_abs"] = float(d.mean())
+    _REPORT[name] = rec
+    print(name, rec)
+    assert rec["safe_fraction"] >= min_safe, rec
+    assert rec["ids_differ_where_safe"] == 0, rec
+    if got_l is not None:
+        assert rec["logits_max_abs"] < tol_max and rec["logits_mean_abs"] < tol_mean, rec
+    return rec
 
 
 def _margin(logits):
@@ -163,12 +206,7 @@ def test_decode_teacher_forced_logits_and_argmax(small):
     n = 48
     ref_t, ref_l = O.greedy_decode(enc, small.weights, cfg, n, True, return_logits=True)
     got_t, got_l = small.decode(enc.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
-    got_t, got_l = got_t.cpu(), got_l.cpu()
-    d = (got_l - ref_l).abs()
-    assert d.max().item() < 0.06 and d.mean().item() < 6e-3
-    safe = _margin(ref_l) >= TAU
-    assert safe.float().mean() > 0.5
-    assert torch.equal(got_t[safe], ref_t[safe])
+    _check_ids("small_teacher_forced", got_t, ref_t, ref_l, got_l)
 
 
 def test_decode_free_running_prefix_and_determinism(small):
@@ -221,7 +259,6 @@ def test_eos_then_pad_fill():
 
 
 def test_early_stop_produces_the_same_tokens_and_stops_launching(small):
-    import time
     cfg = SMALL
     a = O.synthetic_audio(3, cfg, seed=2)
     base = _model(cfg.with_(eos_id=-1))
@@ -234,13 +271,13 @@ def test_early_stop_produces_the_same_tokens_and_stops_launching(small):
     m.set_early_stop(4)
     early = m.decode(e, 64).cpu()
     assert torch.equal(early, full)
-    if all(eos in full[b, 0, :16].tolist() for b in range(3)):     # all rows done early -> far fewer steps were launched
-        torch.cuda.synchronize(); t0 = time.perf_counter(); m.decode(e, 64); torch.cuda.synchronize(); t_early = time.perf_counter() - t0
-        m.set_early_stop(0)
-        torch.cuda.synchronize(); t0 = time.perf_counter(); m.decode(e, 64); torch.cuda.synchronize(); t_full = time.perf_counter() - t0
-        assert t_early < t_full
+    # steps launched = the first multiple of the check interval at which every row has emitted EOS (never timing)
+    last = max((full[b, 0] == eos).nonzero()[0].item() if (full[b, 0] == eos).any() else 64 for b in range(3))
+    expect = min(64, -(-(last + 1) // 4) * 4)
+    assert m.last_decode_steps == expect, (m.last_decode_steps, expect, last)
     m.set_early_stop(0)
     assert torch.equal(m.decode(e, 64).cpu(), full)
+    assert m.last_decode_steps == 64
     m.close()
 
 
@@ -274,9 +311,7 @@ def test_multichannel_rows_share_the_segment_encoder():
     got_t, got_l = m.decode(enc.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
     m.close()
     assert got_t.shape == (2, 3, n)
-    assert (got_l.cpu() - ref_l).abs().max().item() < 0.06
-    safe = _margin(ref_l) >= TAU
-    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+    _check_ids("mc3_teacher_forced", got_t, ref_t, ref_l, got_l)
     assert not torch.equal(ref_t[:, 0], ref_t[:, 1])             # channels really differ
 
 
@@ -288,9 +323,7 @@ def test_multichannel_beyond_128_rows():
     ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, 6, True, return_logits=True)
     got_t, got_l = m.decode(enc.bfloat16().cuda(), 6, forced=ref_t.cuda(), return_logits=True)
     m.close()
-    assert (got_l.cpu() - ref_l).abs().max().item() < 0.06
-    safe = _margin(ref_l) >= TAU
-    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+    _check_ids("mc13_156_rows", got_t, ref_t, ref_l, got_l)
 
 
 @pytest.mark.parametrize("K", [13, 3, 16])
@@ -305,10 +338,7 @@ def test_multichannel_shared_kv_cross_attention(K):
     ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, n, True, return_logits=True)
     got_t, got_l = m.decode(enc.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
     m.close()
-    d = (got_l.cpu() - ref_l).abs()
-    assert d.max().item() < 0.06 and d.mean().item() < 6e-3
-    safe = _margin(ref_l) >= TAU
-    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+    _check_ids(f"mc_shared_kv_K{K}", got_t, ref_t, ref_l, got_l)
 
 
 def test_512_frame_segments():
@@ -319,6 +349,12 @@ def test_512_frame_segments():
     mel = m.logmel(a.cuda())
     assert mel.shape == (2, 512, 128) and (mel.cpu() - mel_ref).abs().max().item() < 1e-3
     assert (m.encode(mel).float().cpu() - enc_ref).abs().max().item() <= 0.0625
+    # decode with 512 cross-attention keys: the cross-attention loop beyond its first 256-key block
+    n = 16
+    ref_t, ref_l = O.greedy_decode(enc_ref, m.weights, cfg, n, True, return_logits=True)
+    got_t, got_l = m.decode(enc_ref.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
+    _check_ids("t512_teacher_forced", got_t, ref_t, ref_l, got_l)
+    _check_stream_prefix(m.decode(enc_ref.bfloat16().cuda(), n).cpu(), ref_t, _margin(ref_l))
     m.close()
 
 
@@ -350,10 +386,7 @@ def _moe_case(cfg, n, tol_max, tol_mean, tau, gap=0.005):
     got_t, got_l = m.decode(enc.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
     stable = (gaps >= gap)[:, None, :]                                                        # (B, 1, steps)
     assert stable.float().mean().item() > 0.5
-    d = (got_l.cpu() - ref_l).abs().amax(-1)
-    assert d[stable].max().item() < tol_max and (got_l.cpu() - ref_l).abs().mean().item() < tol_mean
-    safe = (_margin(ref_l) >= tau) & stable
-    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+    _check_ids(f"moe_fp8{cfg.moe_fp8}", got_t, ref_t, ref_l, got_l, tau=tau, stable=stable, tol_max=tol_max, tol_mean=tol_mean, min_safe=0.4)
     e = enc.bfloat16().cuda()
     assert torch.equal(m.decode(e, n), m.decode(e, n))        # routing + grouped GEMM are reproducible
     return m
@@ -378,24 +411,32 @@ def test_moe_fp8_expert_gemms_match_oracle():
     m.close()
 
 
-def test_full_size_properties_baseline_config_1():
-    """BASELINE configs[1] at full size (64 segments, 256 frames, 1024 tokens) is far beyond what the CPU oracle can
-    check in seconds, so this uses size-independent properties: reproducibility, independence of a segment from the rest
-    of the batch, idempotence under teacher forcing with the model's own output, id range, and the EOS->PAD invariant."""
-    from yourmt3_amd.config import baseline_config
-    cfg = baseline_config(1)
-    m = _model(cfg, max_batch=64)
-    a = O.synthetic_audio(64, cfg, seed=21).cuda()
+def _full_size_properties(cfg, B, seed, probe):
+    """Size-independent properties of one BASELINE config at its full size (far beyond what the CPU oracle checks in
+    seconds): shape / id range, bitwise reproducibility, independence of a segment from the rest of the batch,
+    idempotence under teacher forcing with the model's own output, and a stream that has not collapsed."""
+    m = _model(cfg, max_batch=B)
+    a = O.synthetic_audio(B, cfg, seed=seed).cuda()
+    L = cfg.max_decode_len
     t1 = m.inference(a)
-    assert t1.shape == (64, 1, 1024) and t1.dtype == torch.int32
+    assert t1.shape == (B, cfg.n_channels, L) and t1.dtype == torch.int32
     assert int(t1.min()) >= 0 and int(t1.max()) < cfg.vocab
     assert torch.equal(t1, m.inference(a))                                   # bitwise reproducible
-    for i in (0, 37, 63):                                                    # alone == inside the batch
-        assert torch.equal(m.inference(a[i:i + 1])[0], t1[i])
+    for i in probe:                                                          # alone == inside the batch
+        assert torch.equal(m.inference(a[i:i + 1])[0], t1[i]), i
     enc = m.encode(m.logmel(a))
-    forced = m.decode(enc, 1024, forced=t1)                                  # feeding back its own stream changes nothing
+    forced = m.decode(enc, L, forced=t1)                                     # feeding back its own stream changes nothing
     assert torch.equal(forced, t1)
     assert len(torch.unique(t1)) > 200                                       # not a collapsed stream
+    return m, a, t1
+
+
+def test_full_size_properties_baseline_config_1():
+    """BASELINE configs[1] at full size (64 segments, 256 frames, 1024 tokens), plus the EOS->PAD invariant and continuous
+    batching at full size."""
+    from yourmt3_amd.config import baseline_config
+    cfg = baseline_config(1)
+    m, a, t1 = _full_size_properties(cfg, 64, 21, (0, 37, 63))
     m.close()
     eos = int(t1[5, 0, 100])
     m2 = _model(cfg.with_(eos_id=eos), max_batch=64)
@@ -416,6 +457,48 @@ def test_full_size_properties_baseline_config_1():
     assert bool((t2[5, 0, 101:] == cfg.pad_id).all())
 
 
+def test_full_size_properties_baseline_config_2():
+    """BASELINE configs[2]: Perceiver-TF encoder + T5 decoder, 256 segments x 1024 tokens."""
+    from yourmt3_amd.config import baseline_config
+    m, _, _ = _full_size_properties(baseline_config(2), 256, 22, (0, 129, 255))
+    m.close()
+
+
+def test_full_size_properties_baseline_config_3():
+    """BASELINE configs[3]: 13-channel decoder, 64 segments x 13 channels = 832 rows, 256 tokens per channel."""
+    from yourmt3_amd.config import baseline_config
+    m, _, t = _full_size_properties(baseline_config(3), 64, 23, (0, 41, 63))
+    assert not torch.equal(t[:, 0], t[:, 1])                                 # channels decode different streams
+    m.close()
+
+
+def test_full_size_properties_baseline_config_4():
+    """BASELINE configs[4]: MoE decoder FFN (8 experts, top-2, fp8 expert GEMMs), 64 segments x 1024 tokens."""
+    from yourmt3_amd.config import baseline_config
+    m, _, _ = _full_size_properties(baseline_config(4), 64, 24, (0, 30, 63))
+    m.close()
+
+
+def test_ids_bit_identical_to_round_1():
+    """The decode kernels were restructured in round 2 (fewer dependent launches per step) under the constraint that
+    every sum keeps its round-1 order: free-running greedy ids over hundreds of steps move with the last bit of a logit, so
+    their digests (tests/golden/r01_id_hashes.json, written by the round-1 kernels: tests/scripts/gpu_id_hashes.py) pin it."""
+    import hashlib
+    import importlib.util
+    path = os.path.join(os.path.dirname(__file__), "scripts", "gpu_id_hashes.py")
+    spec = importlib.util.spec_from_file_location("gpu_id_hashes", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref = json.load(open(os.path.join(GOLD, "r01_id_hashes.json")))
+    assert set(ref) <= set(mod.CASES)
+    bad = []
+    for name in ref:
+        cfg, B, L, seed = mod.CASES[name]
+        if mod.digest(cfg, B, L, seed) != ref[name]:
+            bad.append(name)
+    assert not bad, bad
+
+
 def test_perceiver_latent_encoder_matches_oracle():
     """a9 (build-defined spec, parity unpinned w.r.t. the reference): latent array cross-attends to the frames,
     then latent self-attention blocks; decoder unchanged."""
@@ -432,9 +515,7 @@ def test_perceiver_latent_encoder_matches_oracle():
     n = 16
     ref_t, ref_l = O.greedy_decode(enc_ref, m.weights, cfg, n, True, return_logits=True)
     got_t, got_l = m.decode(enc_ref.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
-    assert (got_l.cpu() - ref_l).abs().max().item() < 0.06
-    safe = _margin(ref_l) >= TAU
-    assert torch.equal(got_t.cpu()[safe], ref_t[safe])
+    _check_ids("perceiver_teacher_forced", got_t, ref_t, ref_l, got_l)
     m.close()
     from yourmt3_amd._lib import YMT3Error
     with pytest.raises(YMT3Error):
@@ -596,6 +677,9 @@ def test_against_golden_fixture(name, cfg):
     steps = z["logit_steps"].tolist()
     assert (got_l.cpu()[:, :, steps, :] - torch.from_numpy(z["logits"])).abs().max().item() < 0.06
     safe = margin >= TAU
+    _REPORT["golden_" + name] = {"tau": TAU, "safe_fraction": float(safe.float().mean()),
+                                 "ids_differ_below_tau": int((got_t.cpu()[~safe] != ref_t[~safe]).sum())}
+    assert safe.float().mean().item() >= MIN_SAFE
     assert torch.equal(got_t.cpu()[safe], ref_t[safe])
     free = m.decode(enc_ref.bfloat16().cuda(), n).cpu()
     _check_stream_prefix(free, ref_t, margin)

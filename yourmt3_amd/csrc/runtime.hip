@@ -99,6 +99,7 @@ struct ymt3_ctx {
     bool prof_on = false;
     size_t prof_span_idx = 0;
     bool prof_span_open = false;
+    int last_steps = 0;                     // steps launched by the last decode call (ymt3_last_decode_steps)
     int early_stop_interval = 0;            // ymt3_set_early_stop: host checks `n_unfinished` every N steps (0 = never)
     int* host_flag = nullptr;               // pinned, for that check
     bool debug_hooks = false;               // YMT3_DEBUG_HOOKS=1 at create: ymt3_debug_decode_start is accepted
@@ -607,6 +608,7 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
     int n_chains = (!h->use_graph || prof_stride > 0 || k.dec_ffn == YMT3_FFN_MOE) ? 1 : h->n_chains;   // MoE pair tables are per handle
     if (n_chains > R) n_chains = R;
     LAUNCH(launch_decode_init(a, n_chains, n_steps, step0, tokens, forced, logits_out, s));
+    h->last_steps = n_steps;
     int row0[9];
     row0[0] = 0;
     for (int c = 0; c < n_chains; ++c) row0[c + 1] = row0[c] + R / n_chains + (c < R % n_chains ? 1 : 0);
@@ -666,6 +668,7 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
                 HIP_TRY(hipStreamSynchronize(s));
                 if (*h->host_flag == 0) break;
             }
+            h->last_steps = t;
             LAUNCH(launch_pad_tail(tokens, 0, R, n_steps, t, k.pad_id, s));
         } else if (n_chains == 1) {
             for (int t = 0; t < n_steps; ++t) HIP_TRY(hipGraphLaunch(exec[0], s));
@@ -799,7 +802,9 @@ extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int
     int next = slots, live = slots;
     // every live segment stops within n_steps steps, so the loop is bounded; the guard only catches a logic error
     const long max_rounds = ((long)n_segments / slots + 2) * ((n_steps + interval - 1) / interval + 1);
+    h->last_steps = 0;
     for (long round = 0; live > 0; ++round) {
+        h->last_steps += interval;
         if (round > max_rounds) FAIL(YMT3_ERR_HIP, "slot scheduler made no progress (%d live, %d admitted of %d)", live, next, n_segments);
         for (int i = 0; i < interval; ++i) {
             if (exec) HIP_TRY(hipGraphLaunch(exec, s));
@@ -1016,6 +1021,8 @@ extern "C" int ymt3_ingest(ymt3_handle h, const void* pcm_dev, int pcm_format, i
     HIP_TRY(hipGetLastError());
     return YMT3_OK;
 }
+
+extern "C" int ymt3_last_decode_steps(ymt3_handle h) { return h ? h->last_steps : 0; }
 
 extern "C" int ymt3_set_early_stop(ymt3_handle h, int interval) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");

@@ -68,6 +68,11 @@ class YourMT3:
             raise ValueError(f"batch {audio.shape[0]} exceeds max_batch {self.max_batch}")
         return audio.to(self.device, torch.float32).contiguous()
 
+    @property
+    def last_decode_steps(self) -> int:
+        """Decoder steps the last decode / inference call launched (fewer than asked for after an early stop)."""
+        return int(self._lib.ymt3_last_decode_steps(self._handle))
+
     def set_early_stop(self, interval: int) -> None:
         """Check every `interval` steps whether all rows have emitted EOS and stop decoding once they have (0 = off)."""
         _lib.check(self._lib.ymt3_set_early_stop(self._handle, int(interval)))
