@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define YMT3_ABI_VERSION 1
+#define YMT3_ABI_VERSION 2
 
 enum { YMT3_OK = 0, YMT3_ERR_ARG = 1, YMT3_ERR_BLOB = 2, YMT3_ERR_HIP = 3, YMT3_ERR_UNSUPPORTED = 4 };
 enum { YMT3_ENC_T5 = 0, YMT3_ENC_PERCEIVER_TF = 1 };
@@ -50,6 +50,7 @@ typedef struct ymt3_config {
     int32_t max_decode_len, n_channels, eos_id, pad_id;
     int32_t encoder_type, n_latents;
     int32_t dec_ffn, n_experts, moe_top_k, moe_fp8;
+    int32_t ptf_d, ptf_blocks, ptf_dff;   /* Perceiver-TF encoder: token width (multiple of 64), blocks, FFN width; n_latents = latents per frame */
     int32_t max_batch;              /* segments per call the workspace is sized for */
 } ymt3_config;
 

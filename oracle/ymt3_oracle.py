@@ -201,11 +201,10 @@ def encoder_t5(h: Tensor, W: Dict[str, Tensor], cfg, bf16: bool) -> Tensor:
 
 def encode(audio: Tensor, W: Dict[str, Tensor], cfg, bf16: bool) -> Tuple[Tensor, Tensor]:
     mel = logmel(audio, cfg)
-    h = input_projection(mel, W, bf16)
     if getattr(cfg, "encoder_type", 0) == 1:
         from oracle.perceiver_oracle import encoder_perceiver_tf
-        return mel, encoder_perceiver_tf(h, W, cfg, bf16)
-    return mel, encoder_t5(h, W, cfg, bf16)
+        return mel, encoder_perceiver_tf(mel, W, cfg, bf16)
+    return mel, encoder_t5(input_projection(mel, W, bf16), W, cfg, bf16)
 
 
 # --------------------------------------------------------------------------------------------

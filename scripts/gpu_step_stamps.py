@@ -28,9 +28,11 @@ for name, grid, in0, in1, out0, out1 in rows:
     prev_out = out1
 print(f"step: {rows[-1][5] - rows[0][2]:.2f} us = spans {tot_span:.2f} + gaps {tot_gap:.2f}")
 
-# distribution of workgroup exit times inside the two attention kernels of layer 3 (launch order 22 = self, 24 = cross)
+# distribution of workgroup exit times inside the two attention kernels of layer 3 
 import numpy as np
-for k in ((22, 24) if B == 64 else ()):
+names = [r[0] for r in rows]
+nth = lambda name, n: [i for i, x in enumerate(names) if x == name][n]
+for k in ((nth("self_attn", 3), nth("cross_attn", 3)) if B == 64 else ()):
     name, grid = rows[k][0], rows[k][1]
     st = m.kernel_stamps(k, grid).astype(np.int64)
     st = st[st[:, 0] > 0]                                   # a launcher may use fewer workgroups than the slot reserves

@@ -68,7 +68,7 @@ def main():
     for ws, as_ in ((1234, 0), (7, 11), (99, 5)):
         out.append(case("t5_enc_256f", base, 6, 48, ws, as_))
     out.append(case("t5_enc_512f", base.with_(segment_samples=65535), 2, 24, 1234, 3))
-    out.append(case("perceiver_256f", base.with_(encoder_type=ENC_PERCEIVER_TF, n_latents=256), 4, 32, 21, 2))
+    out.append(case("perceiver_256f", base.with_(encoder_type=ENC_PERCEIVER_TF, n_latents=32, n_enc_layers=0), 4, 32, 21, 2))
     out.append(case("mc13_256f", base.with_(n_channels=13, max_decode_len=32), 3, 20, 1234, 0))
     out.append(case("mc13_256f_seed2", base.with_(n_channels=13, max_decode_len=32), 2, 20, 5, 9))
     out.append(case("moe_bf16_256f", base.with_(dec_ffn=FFN_MOE), 4, 32, 1234, 0, moe_gap=0.005))

@@ -3,7 +3,7 @@ tests/golden/r01_id_hashes.json; tests/test_gpu_parity.py::test_ids_bit_identica
 the summation order of a decode kernel shows up as a changed digest (free-running greedy ids over hundreds of steps move
 with the last bit of a logit).
 
-    python tests/scripts/gpu_id_hashes.py [--write]
+    python tests/scripts/gpu_id_hashes.py [--write] [case names ...]
 """
 import hashlib
 import json
@@ -43,7 +43,10 @@ def digest(cfg, B, L, seed):
 
 def main():
     got = {}
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]           # optional: case names to run
     for name, (cfg, B, L, seed) in CASES.items():
+        if only and name not in only:
+            continue
         got[name] = digest(cfg, B, L, seed)
         print(name, got[name], flush=True)
     if "--write" in sys.argv:

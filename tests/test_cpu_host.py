@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_header_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ymt3_abi_version() == 1
+    assert lib.ymt3_abi_version() == 2
 
 
 def test_cconfig_matches_header_field_order():
@@ -115,6 +115,43 @@ def test_oracle_reproduces_golden_fixture(name, cfg, n):
     assert np.array_equal(f32_to_bf16_bits(enc), z["enc_bf16"])
     toks = O.greedy_decode(enc, W, cfg, n, True)
     assert np.array_equal(toks.numpy(), z["tokens"])
+
+
+def test_perceiver_tf_oracle_shape_mixing_and_blob():
+    """a9 oracle (build-defined spec): (B, T, F') -> latents (B, T, K, D) -> (B, T, d_model); K is free of T; the spectral
+    cross-attention sees one frame, the temporal transformer mixes frames; its attention primitive equals torch's SDPA with
+    scale 1; the blob carries every ptf tensor plus the derived temporal bias table."""
+    import torch
+    from oracle import ymt3_oracle as O
+    from oracle.perceiver_oracle import encoder_perceiver_tf, perceiver_tf_latents, _mha
+    from yourmt3_amd.config import ENC_PERCEIVER_TF
+    from yourmt3_amd.tables import derived_tables
+    from yourmt3_amd.weights import make_weights, pack_blob, unpack_blob
+    cfg = YMT3Config(segment_samples=8191, encoder_type=ENC_PERCEIVER_TF, n_latents=32, n_enc_layers=0, ptf_blocks=2)
+    W = make_weights(cfg)
+    mel = O.logmel(O.synthetic_audio(2, cfg), cfg)
+    z = perceiver_tf_latents(mel, W, cfg, False)
+    assert z.shape == (2, cfg.n_frames, 32, cfg.ptf_d)
+    enc = encoder_perceiver_tf(mel, W, cfg, False)
+    assert enc.shape == (2, cfg.n_frames, cfg.d_model) and torch.isfinite(enc).all()
+    assert torch.allclose(encoder_perceiver_tf(mel[1:], W, cfg, False)[0], enc[1], atol=1e-5)       # segments are independent
+    mel2 = mel.clone(); mel2[0, 0] += 1.0                                                             # perturb frame 0 of segment 0
+    z2 = perceiver_tf_latents(mel2, W, cfg, False)
+    assert (z2[0, -1] - z[0, -1]).abs().max() > 1e-4 and torch.equal(z2[1], z[1])                    # reaches the last frame; not segment 1
+    one = cfg.with_(ptf_blocks=1)
+    W1 = make_weights(one)
+    assert (encoder_perceiver_tf(mel, W1, one, True) - encoder_perceiver_tf(mel, W1, one, False)).abs().mean() < 0.02
+    big = cfg.with_(n_latents=64)
+    assert perceiver_tf_latents(mel, make_weights(big), big, False).shape == (2, cfg.n_frames, 64, cfg.ptf_d)
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(3, 16, 128, generator=g) for _ in range(3))
+    sd = torch.nn.functional.scaled_dot_product_attention
+    ref = sd(q.view(3, 16, 2, 64).transpose(1, 2), k.view(3, 16, 2, 64).transpose(1, 2), v.view(3, 16, 2, 64).transpose(1, 2), scale=1.0)
+    assert torch.allclose(_mha(q, k, v, None, False), ref.transpose(1, 2).reshape(3, 16, 128), atol=1e-5)
+    full = {**W, **derived_tables(W, cfg)}
+    back = unpack_blob(pack_blob(full))
+    assert back["ptf.bias_off"].shape == (cfg.ptf_d // 64, 2 * cfg.n_frames - 1) and back["ptf.1.t.wqkv"].shape == (3 * cfg.ptf_d, cfg.ptf_d)
+    assert back["ptf.out_w"].shape == (cfg.d_model, 32 * cfg.ptf_d)
 
 
 def test_baseline_configs():

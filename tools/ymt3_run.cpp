@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     cfg.d_model = 512; cfg.d_ff = 2048; cfg.n_heads = 8; cfg.d_kv = 64; cfg.n_enc_layers = 6; cfg.n_dec_layers = 6;
     cfg.vocab = 1536; cfg.rel_buckets = 32; cfg.rel_max_distance = 128; cfg.ln_eps = 1e-6f;
     cfg.max_decode_len = 1024; cfg.n_channels = 1; cfg.eos_id = -1; cfg.pad_id = 0;
-    cfg.encoder_type = YMT3_ENC_T5; cfg.n_latents = 256; cfg.dec_ffn = YMT3_FFN_DENSE; cfg.n_experts = 8; cfg.moe_top_k = 2;
+    cfg.encoder_type = YMT3_ENC_T5; cfg.n_latents = 32; cfg.ptf_d = 128; cfg.ptf_blocks = 3; cfg.ptf_dff = 512; cfg.dec_ffn = YMT3_FFN_DENSE; cfg.n_experts = 8; cfg.moe_top_k = 2;
     cfg.max_batch = B;
 
     ymt3_handle h = nullptr;

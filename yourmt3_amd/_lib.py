@@ -73,7 +73,7 @@ def load() -> ctypes.CDLL:
     lib.ymt3_debug_kernel_stamps.restype = i32
     for n in ("ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm"):
         getattr(lib, n).restype = i32
-    if lib.ymt3_abi_version() != 1:
+    if lib.ymt3_abi_version() != 2:
         raise YMT3Error("libymt3_hip.so ABI version mismatch")
     _lib = lib
     return lib

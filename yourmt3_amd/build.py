@@ -15,7 +15,10 @@ OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libymt3_hip.so")
 SOURCES = ["runtime.hip", "frontend.hip", "gemm.hip", "norm.hip", "enc_attn.hip", "decode.hip", "moe.hip", "mc_cross_attn.hip", "ingest.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "ymt3.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+# -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs with the dispatch (gfx950) instead of through a
+# scalar load at the head of the kernel; the decode-step kernels put their operand pointers there (decode.hip)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc() -> str:
@@ -32,16 +35,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, flags=None, lib: str = LIB, obj_dir: str = OBJ) -> str:
+    """`flags` / `lib` / `obj_dir`: A/B builds of the same sources under other compiler flags (scripts/), selected at run
+    time with YMT3_LIB; the product build uses the defaults."""
+    flags = FLAGS if flags is None else flags
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -53,12 +59,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 def build_tools(force: bool = False) -> str:

@@ -51,11 +51,15 @@ class YMT3Config:
     pad_id: int = PAD_ID
     # --- architecture variants ---
     encoder_type: int = ENC_T5        # ENC_PERCEIVER_TF for config 3
-    n_latents: int = 256              # Perceiver latent array length (= decoder cross-attention length; must equal n_frames)
+    n_latents: int = 32               # Perceiver-TF: latents per frame (32 or 64; independent of the frame count)
     dec_ffn: int = FFN_DENSE          # FFN_MOE for config 5
     n_experts: int = 8
     moe_top_k: int = 2
     moe_fp8: int = 0                  # 1: expert GEMMs on OCP e4m3 MFMA (per-expert weight scale, per-row activation scale)
+    # --- Perceiver-TF encoder (oracle/perceiver_oracle.py) ---
+    ptf_d: int = 128                  # latent / spectral-token width (heads of 64)
+    ptf_blocks: int = 3               # [spectral cross-attention, latent transformer, temporal transformer] x blocks
+    ptf_dff: int = 512                # FFN width inside the three sub-layers
 
     @property
     def n_frames(self) -> int:
@@ -94,6 +98,7 @@ class CConfig(ctypes.Structure):
         ("eos_id", ctypes.c_int32), ("pad_id", ctypes.c_int32),
         ("encoder_type", ctypes.c_int32), ("n_latents", ctypes.c_int32),
         ("dec_ffn", ctypes.c_int32), ("n_experts", ctypes.c_int32), ("moe_top_k", ctypes.c_int32), ("moe_fp8", ctypes.c_int32),
+        ("ptf_d", ctypes.c_int32), ("ptf_blocks", ctypes.c_int32), ("ptf_dff", ctypes.c_int32),
         ("max_batch", ctypes.c_int32),
     ]
 
@@ -116,7 +121,7 @@ def baseline_config(i: int) -> YMT3Config:
     if i == 1:      # MT3 base (T5-small) bf16, batch 64, 1024-token decoder
         return base.with_(eos_id=-1)
     if i == 2:      # Perceiver-TF encoder + T5 decoder, batch 256
-        return base.with_(encoder_type=ENC_PERCEIVER_TF, n_latents=base.n_frames, eos_id=-1)
+        return base.with_(encoder_type=ENC_PERCEIVER_TF, n_latents=32, n_enc_layers=0, eos_id=-1)
     if i == 3:      # 13-channel multi-track decoder, 256 tokens per channel
         return base.with_(n_channels=13, max_decode_len=256, eos_id=-1)
     if i == 4:      # MoE decoder FFN (8 experts)

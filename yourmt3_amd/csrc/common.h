@@ -24,6 +24,17 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// A product and a sum that must stay two roundings (hipcc contracts a*b + c into an fma by default, and __fmul_rn / __fadd_rn are
+// plain operators to it): the pragma strips the `contract` flag from these two operations only.
+__device__ __forceinline__ float mul_sep(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_sep(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -42,6 +53,15 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
     f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
     f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
     f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+// One wave-instruction of direct global -> LDS DMA: every lane's 16 bytes land at lds_dst + 16 * lane (1 KiB, linear).  Inline asm,
+// so hipcc neither counts it in its vmcnt bookkeeping nor orders LDS reads behind it: the issuing wave waits with an explicit
+// `s_waitcnt vmcnt(n)` (older DMAs retire before younger loads: vector-memory data returns in issue order).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 #define HIP_TRY(expr)                                                                      \

@@ -31,6 +31,7 @@
 namespace {
 
 constexpr int DKV = 64;
+constexpr int WO_LDS_BYTES = 8 * 64 * 128;     // folded O-projection: the head's 64 k of all 512 wo rows
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Measurement only (YMT3_STAMP=1 at ymt3_create; the pointer is null otherwise): constant-rate wall clock (100 MHz) at the
@@ -60,7 +61,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // to about one per CU -- at two per CU the second one's operands queue behind the first's and the kernel's last exit came
 // 1.1 us after its first (profiles/r01_step_stamps.txt) -- and the activation strip is read once for both.
 template <int MODE, int K, int NT>
-__global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
+__global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict__ pW, const void* __restrict__ pX, const float* __restrict__ pGain,
+                                                       float* pSsq, float* pOut, int row0, int R, int N, int ssq_stride, DecGemmArgs a) {
+    // The operand pointers and the tile geometry are LEADING SCALAR kernel arguments (14 dwords): built with
+    // -mllvm -amdgpu-kernarg-preload-count=16 they arrive in SGPRs with the dispatch instead of through a scalar load at the head
+    // of the kernel's critical path (every global load's address depends on them).  `a` carries the rest, read when needed.
     constexpr bool NORM = (MODE != DG_RESID);
     constexpr int KW = K / 8;            // K slice per wave
     constexpr int KS = KW / 32;          // MFMA k-steps per wave
@@ -69,7 +74,6 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     constexpr int STRIP = 16 * PITCH;    // one operand strip (16 rows) of one wave
     static_assert(MODE != DG_RESID || NT == 1, "the RESID epilogue writes one sum(h^2) partial per 16-column tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    STAMP_IN(a);
     float* red = reinterpret_cast<float*>(smem);                    // [8][ROWS][COLS]
     float* sscale = red + 8 * ROWS * COLS;                          // [ROWS]
     char* strips = smem + (8 * ROWS * COLS + ROWS) * 4;             // [8 waves][A strip | NT W strips]
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     const int li = lane & 15, g = lane >> 4;
     // block -> (n tile, m tile): blocks with equal blockIdx % 8 (one XCD under round-robin placement;
     // speed only) walk the m tiles of one n tile back to back
-    const int n_mt = (a.R + ROWS - 1) / ROWS, n_nt = a.N / COLS;
+    const int n_mt = (R + ROWS - 1) / ROWS, n_nt = N / COLS;
     int nt_idx, mt_idx;
     if ((n_nt & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
         mt_idx = blockIdx.x % n_mt;
         nt_idx = blockIdx.x / n_mt;
     }
-    const int n0 = nt_idx * COLS, m0 = a.row0 + mt_idx * ROWS, m_end = a.row0 + a.R;
+    const int n0 = nt_idx * COLS, m0 = row0 + mt_idx * ROWS, m_end = row0 + R;
 
     // epilogue ownership: thread -> (row mr, 2 columns nq)
     const bool epi = tid < ROWS * 8 * NT;
@@ -96,8 +100,13 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     const int m = m0 + mr, n = n0 + nq;
     const bool live = epi && m < m_end;
     float2 hold = make_float2(0.f, 0.f);
+    float2 hp[8];                                // DG_RESID with a.part: the eight per-head partials of the folded O-projection
     if constexpr (MODE == DG_RESID) {
-        if (live) hold = *reinterpret_cast<const float2*>(a.out_f32 + (size_t)m * a.N + n);   // prefetch the RMW operand
+        if (live) hold = *reinterpret_cast<const float2*>(pOut + (size_t)m * N + n);   // prefetch the RMW operand
+        if (a.part && live) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) hp[w] = *reinterpret_cast<const float2*>(a.part + ((size_t)m * 8 + w) * N + n);
+        }
     }
     int step = 0;                                // cache position of the KV append: requested now, not as a round trip in the epilogue
     if constexpr (MODE == DG_NORM_QKV_CACHE) step = a.row_pos ? a.row_pos[m < m_end ? m : m_end - 1] : a.shared->step;
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NIW; ++i) {
             const int row = i * RPIW + lane / LPRW, ch = lane % LPRW;
-            wv[i] = *reinterpret_cast<const u32x4*>(a.W + (size_t)(n0 + row) * K + wave * KW + ch * 8);
+            wv[i] = *reinterpret_cast<const u32x4*>(pW + (size_t)(n0 + row) * K + wave * KW + ch * 8);
         }
         if constexpr (NORM) {
             constexpr int LPRX = KW * 4 / 16, RPIX = 64 / LPRX, NIX = 16 / RPIX;   // fp32 rows
@@ -124,16 +133,17 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             for (int i = 0; i < NIX; ++i) {
                 int mm = m0 + i * RPIX + lane / LPRX;
                 mm = mm < m_end ? mm : m_end - 1;
-                xv[i] = *reinterpret_cast<const f32x4*>(a.x_f32 + (size_t)mm * K + wave * KW + (lane % LPRX) * 4);
+                xv[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(pX) + (size_t)mm * K + wave * KW + (lane % LPRX) * 4);
             }
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gain + wave * KW + (lane % LPRX) * 4);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(pGain + wave * KW + (lane % LPRX) * 4);
             float ss = 0.f;
             if (tid < ROWS * 8) {                                    // 8 threads per row, 4 of the 32 partials each
                 const int mm = m0 + (tid >> 3) < m_end ? m0 + (tid >> 3) : m_end - 1;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ss += a.ssq[(size_t)((tid & 7) * 4 + j) * a.ssq_stride + mm];
+                for (int j = 0; j < 4; ++j) ss += pSsq[(size_t)((tid & 7) * 4 + j) * ssq_stride + mm];
             }
             __builtin_amdgcn_sched_barrier(0);   // every operand load is in flight before anything waits
+            STAMP_IN(a);                         // (reads a.stamp from the kernarg segment: after the loads, not in front of them)
             ss += __shfl_xor(ss, 1, 64);
             ss += __shfl_xor(ss, 2, 64);
             ss += __shfl_xor(ss, 4, 64);
@@ -156,9 +166,10 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
             for (int i = 0; i < NIA; ++i) {
                 int mm = m0 + i * RPIW + lane / LPRW;
                 mm = mm < m_end ? mm : m_end - 1;
-                av[i] = *reinterpret_cast<const u32x4*>(a.a_bf16 + (size_t)mm * K + wave * KW + (lane % LPRW) * 8);
+                av[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(pX) + (size_t)mm * K + wave * KW + (lane % LPRW) * 8);
             }
             __builtin_amdgcn_sched_barrier(0);   // every operand load is in flight before anything waits
+            STAMP_IN(a);
 #pragma unroll
             for (int i = 0; i < NIW; ++i) {
                 const int off = (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16;
@@ -198,17 +209,23 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     if constexpr (MODE == DG_RESID) {
         float2 o = make_float2(0.f, 0.f);
         if (live) {
+            if (a.part) {                         // h + (p0 + ... + p7): what the separate O-projection launch left in h
+                float2 sp = hp[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) { sp.x += hp[w].x; sp.y += hp[w].y; }
+                hold.x += sp.x; hold.y += sp.y;
+            }
             o = make_float2(hold.x + s.x, hold.y + s.y);
-            *reinterpret_cast<float2*>(a.out_f32 + (size_t)m * a.N + n) = o;
+            *reinterpret_cast<float2*>(pOut + (size_t)m * N + n) = o;
         }
         // this tile's share of sum(h^2) for the next norm
         float q = o.x * o.x + o.y * o.y;
         q += __shfl_xor(q, 1, 64);
         q += __shfl_xor(q, 2, 64);
         q += __shfl_xor(q, 4, 64);
-        if (live && (tid & 7) == 0) a.ssq[(size_t)nt_idx * a.ssq_stride + m] = q;
+        if (live && (tid & 7) == 0) pSsq[(size_t)nt_idx * ssq_stride + m] = q;
     } else if constexpr (MODE == DG_NORM_LOGITS) {
-        if (live) *reinterpret_cast<float2*>(a.out_f32 + (size_t)m * a.N + n) = s;
+        if (live) *reinterpret_cast<float2*>(pOut + (size_t)m * N + n) = s;
     } else if (live) {
         if constexpr (MODE == DG_NORM_BF16_RELU) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); }
         const uint32_t pk = pack_bf16x2(s.x, s.y);
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
                 *reinterpret_cast<uint32_t*>(cache + (((size_t)m * a.H + hh) * a.L + step) * DKV + dd) = pk;
             }
         } else {
-            *reinterpret_cast<uint32_t*>(a.out_bf16 + (size_t)m * a.N + n) = pk;
+            *reinterpret_cast<uint32_t*>(a.out_bf16 + (size_t)m * N + n) = pk;
         }
     }
     STAMP_OUT(a);
@@ -248,43 +265,78 @@ __device__ __forceinline__ float sum8(float v) {
 // each only add dispatch rounds.
 // (Two rows per workgroup sharing the head's projection weights -- half the weight reads from L2 -- was measured and is
 // slower: 10.2 vs 8.7 us, eight waves per CU keep too little of the K/V stream in flight; profiles/r01_step_stamps.txt.)
-template <bool SELF, bool FUSEQ, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {   // 4 waves / SIMD -> <= 128 VGPRs
+// OP (O-projection partials; 8 waves only).  SELF: the kernel ends with its head's share of the output projection,
+// opart[r][h][:] = R(o) . wo[:, 64h..64h+64)^T -- the same two chained MFMAs over the same 64 k as wave h of the DG_RESID kernel, so
+// the values are that kernel's split-K partials bit for bit; the 64 weight rows x 128 B of every wave come in by LDS DMA issued
+// before the K/V stream (L2 hits, no registers) and sit in LDS until the tail.  FUSEQ cross-attention: the residual row is
+// h + (p0 + ... + p7), summed in wave order as DG_RESID's reduction does, and sum(x^2) is rebuilt with DG_RESID's tree
+// (pairs, then the 16-column tiles) followed by the 32-tile wave sum the ssq consumers use: one launch less per layer, same bits.
+template <bool SELF, bool FUSEQ, int NW, bool OP = false>
+__global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __restrict__ pK, const bf16_t* __restrict__ pV, const bf16_t* __restrict__ pQ,
+                                                              const float* __restrict__ pF, const void* __restrict__ p4, const void* __restrict__ p5,
+                                                              unsigned geom0, unsigned geom1, DecAttnArgs a) {   // 4 waves / SIMD -> <= 128 VGPRs
+    // Leading scalar arguments (14 dwords; kernarg preload, see dec_gemm_kernel) -- everything the first loads' addresses depend
+    // on: K / V slab bases, pQ = q (wq when FUSEQ), pF = the position-bias table (SELF) or the residual stream (FUSEQ),
+    // p4 / p5 = loop state and per-row positions (SELF) or norm gain and sum(h^2) partials / O-projection partials (FUSEQ),
+    // geom0 = row0 | rows_per_kv << 16 | H << 24, geom1 = slab_keys | n_keys_const << 20.
+    const int row0 = geom0 & 0xffff, rows_per_kv = (geom0 >> 16) & 0xff, H = geom0 >> 24;
+    const int slab_keys = geom1 & 0xfffff, n_keys_const = geom1 >> 20;
+    const DecodeShared* pShared = static_cast<const DecodeShared*>(p4);
+    const int* pRowPos = static_cast<const int*>(p5);
+    const float* pGain = static_cast<const float*>(p4);
+    const float* pPart = static_cast<const float*>(p5);
+    static_assert(!OP || NW == 8, "the folded O-projection maps wave w to output columns [64w, 64w + 64)");
     __shared__ float sm[NW], sl[NW], sacc[NW][DKV];
     __shared__ __attribute__((aligned(16))) float xs[FUSEQ ? 512 : 4];
     __shared__ __attribute__((aligned(16))) bf16_t qs[DKV];
     __shared__ float s_scale;
+    __shared__ float s_tile[OP && FUSEQ ? SSQ_TILES : 1];
+    extern __shared__ __attribute__((aligned(1024))) char wo_lds[];      // OP && SELF: [8 waves][64 rows][128 B], chunks XOR-swizzled by row
     const int tid = threadIdx.x, lane = tid & 63;
-    STAMP_IN(a);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane & 7, kg = lane >> 3;
-    const int r = a.row0 + blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const int n_keys = SELF ? (a.row_pos ? a.row_pos[r] : a.shared->step) + 1 : a.n_keys_const;
-    const int kv_row = r / a.rows_per_kv;
-    const size_t slab = ((size_t)kv_row * a.H + h) * a.slab_keys * DKV;
-    const bf16_t* kb = a.k + slab + sub * 8;
-    const bf16_t* vb = a.v + slab + sub * 8;
-    const float* bias = SELF ? a.bias + (size_t)h * a.bias_stride : nullptr;
+    const int r = row0 + blockIdx.x / H, h = blockIdx.x % H;
+    const int n_keys = SELF ? (pRowPos ? pRowPos[r] : pShared->step) + 1 : n_keys_const;
+    const int kv_row = r / rows_per_kv;
+    const size_t slab = ((size_t)kv_row * H + h) * slab_keys * DKV;
+    const bf16_t* kb = pK + slab + sub * 8;
+    const bf16_t* vb = pV + slab + sub * 8;
+    const float* bias = SELF ? pF + (size_t)h * slab_keys : nullptr;      // the bias table's row pitch is the cache length (launcher checks)
+    if constexpr (OP && SELF) {
+        // this wave's 64 rows of wo (output columns 64w..64w+63), the head's 64 k each: 8 DMAs of 8 rows x 128 B.  LDS slot
+        // (row, pos) holds source chunk pos ^ (row & 7): the swizzle sits on the source address, the DMA writes linearly
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wo_lds + (unsigned)wave * 8192u;
+        const bf16_t* src = a.wo + ((size_t)(wave * 64 + (lane >> 3)) * H + h) * DKV + ((lane & 7) ^ (lane >> 3)) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds16(src + (size_t)i * 8 * H * DKV, lds0 + (unsigned)i * 1024u);
+    }
 
     // q stays packed (4 x bf16x2); halves are widened to fp32 at use
     u32x4 qp;
     u32x4 wq_v[FUSEQ ? 8 : 1];
     float x_v = 0.f, g_v = 0.f, ss = 0.f;
+    float pv[OP && FUSEQ ? 8 : 1];
     if constexpr (FUSEQ) {
         // operands of the fused projection: wave w owns outputs 8w..8w+7, lane l the k-chunk 8l..8l+7
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
-            wq_v[jj] = *reinterpret_cast<const u32x4*>(a.wq + ((size_t)h * DKV + wave * 8 + jj) * 512 + lane * 8);
-        x_v = a.x_f32[(size_t)r * 512 + tid];
-        g_v = a.gain[tid];
-        if (tid < SSQ_TILES) ss = a.ssq[(size_t)tid * a.ssq_stride + r];
+            wq_v[jj] = *reinterpret_cast<const u32x4*>(pQ + ((size_t)h * DKV + wave * 8 + jj) * 512 + lane * 8);
+        x_v = pF[(size_t)r * 512 + tid];
+        g_v = pGain[tid];
+        if constexpr (OP) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) pv[w] = pPart[((size_t)r * H + w) * 512 + tid];
+        } else {
+            if (tid < SSQ_TILES) ss = pPart[(size_t)tid * a.ssq_stride + r];
+        }
     } else {
-        qp = *reinterpret_cast<const u32x4*>(a.q + ((size_t)r * a.H + h) * DKV + sub * 8);
+        qp = *reinterpret_cast<const u32x4*>(pQ + ((size_t)r * H + h) * DKV + sub * 8);
     }
 
     float m = -1.0e30f, l = 0.f, acc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.f;
+    STAMP_IN(a);                               // (reads a.stamp from the kernarg segment: behind the first loads, not in front of them)
 
     // The self-attention cache (up to 805 MB) is read exactly once per step: non-temporal loads keep it
     // from evicting the weights (42 MB) and the cross-attention K/V (201 MB at 64 segments), both
@@ -393,6 +445,22 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
         }
     }
     if constexpr (FUSEQ) {
+        if constexpr (OP) {
+            // x = h + (p0 + p1 + ... + p7), then DG_RESID's sum(x^2) tree: (x_even^2 + x_odd^2), the 8 pairs of a 16-column
+            // tile by xor 1, 2, 4 -- mul_sep / add_sep: the epilogue this mirrors multiplies (v_pk_mul) and adds, never an fma
+            float sp = pv[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) sp += pv[w];
+            x_v += sp;
+            float q2 = mul_sep(x_v, x_v);
+            q2 = add_sep(q2, __shfl_xor(q2, 1, 64));
+            q2 = add_sep(q2, __shfl_xor(q2, 2, 64));
+            q2 = add_sep(q2, __shfl_xor(q2, 4, 64));
+            q2 = add_sep(q2, __shfl_xor(q2, 8, 64));
+            if ((tid & 15) == 0) s_tile[tid >> 4] = q2;
+            __syncthreads();
+            ss = tid < SSQ_TILES ? s_tile[tid] : 0.f;
+        }
         // norm scale (fixed-order tree over the 32 partials), normed row -> LDS as bf16-rounded floats
         ss = wave_sum(ss);
         if (tid == 0) s_scale = rsqrtf(ss / 512.f + a.eps);
@@ -452,7 +520,34 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(DecAttnArgs a) {  
             L += sl[w] * e;
             o += sacc[w][tid] * e;
         }
-        a.out[((size_t)r * a.H + h) * DKV + tid] = f2bf(o / L);
+        if constexpr (OP && SELF) qs[tid] = f2bf(o / L);        // the projection's operand; nobody reads a.out in this mode
+        else a.out[((size_t)r * H + h) * DKV + tid] = f2bf(o / L);
+    }
+    if constexpr (OP && SELF) {
+        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's own wo rows have landed (nobody else reads them)
+        const int li = lane & 15, g = lane >> 4;
+        const char* strip = wo_lds + wave * 8192;
+        f32x4 pa[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // activation operand: row 0 of the 16-row tile is (r, h)'s output, rows 1..15 are zero (their results are not stored)
+            bf16x8 af = *reinterpret_cast<const bf16x8*>(qs + ks * 32 + g * 8);
+            if (li != 0) af = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int row = c * 16 + li;
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(strip + row * 128 + (((ks * 4 + g) ^ (row & 7)) * 16));
+                pa[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, pa[c], 0, 0, 0);
+            }
+        }
+        if (li == 0) {
+            float* dst = a.opart + ((size_t)r * H + h) * 512 + wave * 64 + g * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(dst + c * 16) = make_float4(pa[c][0], pa[c][1], pa[c][2], pa[c][3]);
+        }
     }
     STAMP_OUT(a);
 }
@@ -474,29 +569,32 @@ __device__ __forceinline__ void embed_row(const ArgmaxArgs& a, int r, const bf16
     if (tid < SSQ_TILES) a.ssq[(size_t)tid * a.ssq_stride + r] = tid == 0 ? (scratch4[0] + scratch4[1]) + (scratch4[2] + scratch4[3]) : 0.f;
 }
 
-__global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
+__global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restrict__ pLogits, DecodeShared* pShared, int* pFinished, int* pRowPos,
+                                                           const long long* __restrict__ pRowOut, const bf16_t* __restrict__ pEmbed, int row0, int V,
+                                                           ArgmaxArgs a) {
+    // leading scalar arguments: kernarg preload (see dec_gemm_kernel)
     __shared__ float sv[4];
     __shared__ int si[4];
     __shared__ int s_feed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    STAMP_IN(a);
-    const int r = a.row0 + blockIdx.x;
-    DecodeShared* sh = a.shared;
+    const int r = row0 + blockIdx.x;
+    DecodeShared* sh = pShared;
     const int t = sh->step, n_steps = sh->n_steps, col = t - sh->step0;   // col: index within this call
-    const float* row = a.logits + (size_t)r * a.V;
+    const float* row = pLogits + (size_t)r * V;
     // everything thread 0 needs after the argmax is requested now (workgroup-uniform addresses), under the logits loads,
     // instead of as a chain of round trips behind them
     int32_t* const tokens_out = sh->tokens_out;
     const int32_t* const forced = sh->forced;
     float* const logits_out = sh->logits_out;
-    const int was_finished = a.finished[r];
+    const int was_finished = pFinished[r];
     const int forced_tok = forced ? forced[(size_t)r * n_steps + col] : 0;
-    const int pos0 = a.row_pos ? a.row_pos[r] : 0;
-    const long long out0 = a.row_pos ? a.row_out[r] : 0;
+    const int pos0 = pRowPos ? pRowPos[r] : 0;
+    const long long out0 = pRowPos ? pRowOut[r] : 0;
 
+    STAMP_IN(a);
     float bv = -3.4e38f;
     int bi = 0x7fffffff;
-    for (int i = tid; i < a.V; i += 256) {
+    for (int i = tid; i < V; i += 256) {
         const float v = row[i];
         if (v > bv) { bv = v; bi = i; }       // ascending i: the first maximum is kept
     }
@@ -508,7 +606,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
     }
     if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
     __syncthreads();
-    if (tid == 0 && a.row_pos) {
+    if (tid == 0 && pRowPos) {
         // slot mode: this row's own position; a stopped row writes nothing and stays where it is (its slot is refilled
         // by the host), a live one stops after EOS or its n_steps-th token
 #pragma unroll
@@ -518,8 +616,8 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
         if (!was_finished) {
             const int p = pos0;
             tokens_out[out0 + p] = bi;
-            if ((a.eos_id >= 0 && bi == a.eos_id) || p + 1 >= n_steps) a.finished[r] = 1;
-            else a.row_pos[r] = p + 1;
+            if ((a.eos_id >= 0 && bi == a.eos_id) || p + 1 >= n_steps) pFinished[r] = 1;
+            else pRowPos[r] = p + 1;
             feed = bi;
         }
         s_feed = feed;
@@ -530,20 +628,20 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
         int tok = bi;
         if (a.eos_id >= 0) {
             if (was_finished) tok = a.pad_id;
-            else if (tok == a.eos_id) a.finished[r] = 1;
+            else if (tok == a.eos_id) pFinished[r] = 1;
         }
         tokens_out[(size_t)r * n_steps + col] = tok;
         int feed = forced ? forced_tok : tok;
-        s_feed = feed < 0 ? 0 : (feed >= a.V ? a.V - 1 : feed);       // caller-supplied ids must not index outside the table
+        s_feed = feed < 0 ? 0 : (feed >= V ? V - 1 : feed);       // caller-supplied ids must not index outside the table
     }
     __syncthreads();
     const int feed = s_feed;
-    const bf16_t* e = a.embed + (size_t)feed * a.d;
+    const bf16_t* e = pEmbed + (size_t)feed * a.d;
     const bf16_t* c = a.chan_embed ? a.chan_embed + (size_t)(r % a.n_channels) * a.d : nullptr;
     embed_row(a, r, e, c, sv);
-    if (logits_out && !a.row_pos) {
-        float* dst = logits_out + ((size_t)r * n_steps + col) * a.V;
-        for (int i = tid; i < a.V; i += 256) dst[i] = row[i];
+    if (logits_out && !pRowPos) {
+        float* dst = logits_out + ((size_t)r * n_steps + col) * V;
+        for (int i = tid; i < V; i += 256) dst[i] = row[i];
     }
     // the last workgroup to finish advances the position; every workgroup has read `t` by then
     __syncthreads();
@@ -555,7 +653,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(ArgmaxArgs a) {
             sh->step = t + 1;
             if (a.eos_id >= 0) {             // the fence above makes every row's flag visible to this last arriver
                 int n = 0;
-                for (int i = 0; i < (int)gridDim.x; ++i) n += a.finished[a.row0 + i] ? 0 : 1;
+                for (int i = 0; i < (int)gridDim.x; ++i) n += pFinished[row0 + i] ? 0 : 1;
                 sh->n_unfinished = n;
             }
         }
@@ -619,7 +717,9 @@ int launch_dg(const DecGemmArgs& a, hipStream_t stream) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, NT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K, NT>()) == hipSuccess ? 0 : -2;
     if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;   // the norm consumers sum exactly SSQ_TILES partials
-    dec_gemm_kernel<MODE, K, NT><<<(a.N / (16 * NT)) * ((a.R + 15) / 16), 512, dg_lds_bytes<MODE, K, NT>(), stream>>>(a);
+    dec_gemm_kernel<MODE, K, NT><<<(a.N / (16 * NT)) * ((a.R + 15) / 16), 512, dg_lds_bytes<MODE, K, NT>(), stream>>>(
+        a.W, MODE == DG_RESID ? static_cast<const void*>(a.a_bf16) : static_cast<const void*>(a.x_f32), a.gain, a.ssq, a.out_f32, a.row0, a.R, a.N,
+        a.ssq_stride, a);
     return 0;
 }
 
@@ -648,6 +748,8 @@ int init_decode_kernels() {
     rc |= launch_dg<DG_NORM_BF16, 512, 2>(z, nullptr);
     rc |= launch_dg<DG_NORM_BF16_RELU, 512, 2>(z, nullptr);
     rc |= launch_dg<DG_NORM_LOGITS, 512, 2>(z, nullptr);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WO_LDS_BYTES) != hipSuccess) rc |= -2;
     return rc;
 }
 
@@ -673,21 +775,32 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
     const bool many = a.R * a.H > 2048;
+    if ((a.wo || a.ipart) && (many || a.H != 8 || (a.wo && !a.opart) || (a.ipart && !a.wq))) return -1;   // folded O-projection: 8 heads, 8-wave kernels
+    if (a.row0 < 0 || a.row0 > 0xffff || a.rows_per_kv < 1 || a.rows_per_kv > 0xff || a.H < 1 || a.H > 0xff || a.slab_keys < 1 || a.slab_keys > 0xfffff ||
+        a.n_keys_const < 0 || a.n_keys_const > 0xfff || (self_attn && a.bias_stride != a.slab_keys))
+        return -1;                                                                     // the packed geometry words
+    const unsigned g0 = (unsigned)a.row0 | (unsigned)a.rows_per_kv << 16 | (unsigned)a.H << 24, g1 = (unsigned)a.slab_keys | (unsigned)a.n_keys_const << 20;
+    const int grid = a.R * a.H;
+#define ATTN(S, F, W, O, THREADS, LDS, PQ, PF, P4, P5) dec_attn_kernel<S, F, W, O><<<grid, THREADS, LDS, stream>>>(a.k, a.v, PQ, PF, P4, P5, g0, g1, a)
     if (self_attn) {
-        if (many) dec_attn_kernel<true, false, 2><<<a.R * a.H, 128, 0, stream>>>(a);
-        else dec_attn_kernel<true, false, 8><<<a.R * a.H, 512, 0, stream>>>(a);
+        if (a.wo) ATTN(true, false, 8, true, 512, WO_LDS_BYTES, a.q, a.bias, a.shared, a.row_pos);
+        else if (many) ATTN(true, false, 2, false, 128, 0, a.q, a.bias, a.shared, a.row_pos);
+        else ATTN(true, false, 8, false, 512, 0, a.q, a.bias, a.shared, a.row_pos);
     } else if (a.wq) {
-        dec_attn_kernel<false, true, 8><<<a.R * a.H, 512, 0, stream>>>(a);       // the fused projection maps one thread per d_model element
+        // the fused projection maps one thread per d_model element
+        if (a.ipart) ATTN(false, true, 8, true, 512, 0, a.wq, a.x_f32, a.gain, a.ipart);
+        else ATTN(false, true, 8, false, 512, 0, a.wq, a.x_f32, a.gain, a.ssq);
     } else {
-        if (many) dec_attn_kernel<false, false, 2><<<a.R * a.H, 128, 0, stream>>>(a);
-        else dec_attn_kernel<false, false, 8><<<a.R * a.H, 512, 0, stream>>>(a);
+        if (many) ATTN(false, false, 2, false, 128, 0, a.q, nullptr, nullptr, nullptr);
+        else ATTN(false, false, 8, false, 512, 0, a.q, nullptr, nullptr, nullptr);
     }
+#undef ATTN
     return 0;
 }
 
 int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
-    argmax_embed_kernel<<<a.R, 256, 0, stream>>>(a);
+    argmax_embed_kernel<<<a.R, 256, 0, stream>>>(a.logits, a.shared, a.finished, a.row_pos, a.row_out, a.embed, a.row0, a.V, a);
     return 0;
 }
 

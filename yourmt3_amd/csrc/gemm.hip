@@ -236,11 +236,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 constexpr int TM = 256, TN = 128, NST = 3;
 constexpr int STAGE_BYTES = (TM + TN) * BK * 2;      // 48 KB: A rows, then W rows, 128 B each
 
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 #define WAIT_DMA_AND_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <int EPI>

@@ -60,6 +60,22 @@ int launch_enc_attention_qkv(const bf16_t* q, int ldq, const bf16_t* k, const bf
                              bf16_t* out, int B, int T, int H, hipStream_t stream);
 int launch_enc_attention(const bf16_t* qkv, const float* bias_off, bf16_t* out, int B, int T, int H, hipStream_t stream);
 
+// Batched small-sequence attention for the Perceiver-TF encoder (a9): n_seq independent sequences, heads of 64, Tq queries
+// over Tk keys per sequence.  Sequence s starts at element (s / inner_n) * outer + (s % inner_n) * inner of each buffer and
+// its consecutive positions are `step` elements apart -- so the same kernel serves sequences that are contiguous runs of rows
+// (spectral cross-attention and latent self-attention: one sequence per (segment, frame)) and sequences strided through
+// them (temporal self-attention: one sequence per (segment, latent), positions = frames).
+struct SeqAttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* out;
+    const float* bias_off;        // [H][2*Tk-1] by key - query + Tk - 1 (needs Tq == Tk), or null: no bias
+    int n_seq, H, Tq, Tk, inner_n;
+    long long q_outer, q_inner, q_step, kv_outer, kv_inner, kv_step, o_outer, o_inner, o_step;
+};
+int launch_seq_attention(const SeqAttnArgs& a, hipStream_t stream);
+// spectral tokens of the Perceiver-TF encoder: out bf16 [n_rows][d] = R(rmsnorm(mel[row] * w + pos[row % F]) * gain)
+int launch_spec_embed(const float* mel, const float* w, const bf16_t* pos, const float* gain, bf16_t* out, long long n_rows, int F, int d,
+                      float eps, hipStream_t stream);
+
 // ---------------------------------------------------------------- decoder step (decode.hip)
 struct DecodeShared {           // device-resident loop state, read by every decode kernel
     int step;                   // position being decoded (tokens already in the cache)
@@ -93,6 +109,9 @@ struct DecGemmArgs {
     unsigned long long* stamp;  // measurement (YMT3_STAMP=1): [grid][2] wall-clock entry / exit per workgroup; else null
     float* ssq;                 // [SSQ_TILES][ssq_stride] per-row partial sums of h^2 (read by NORM, written by RESID)
     int ssq_stride;
+    // MODE_RESID only, or null: per-head O-projection partials [R][H][N] left by the self-attention kernel; the residual
+    // operand becomes h + (p0 + p1 + ... + p7) -- the sum the separate O-projection launch would have stored in h
+    const float* part;
 };
 enum DecGemmMode { DG_NORM_QKV_CACHE = 0, DG_NORM_BF16 = 1, DG_NORM_BF16_RELU = 2, DG_NORM_LOGITS = 3, DG_RESID = 4 };
 int init_decode_kernels();
@@ -117,6 +136,13 @@ struct DecAttnArgs {
     const float* gain;          // [512]
     const float* ssq; int ssq_stride;
     float eps;
+    // O-projection folded into the self-attention kernel (wo != nullptr; self, 8 waves per (row, head)): the kernel ends with
+    // its head's share of the projection, opart[r][h][0..512) = R(o_h) . wo[:, 64h..64h+64)^T, exactly the wave-h split-K partial
+    // of the DG_RESID kernel; the fused cross-attention (ipart != nullptr) and the cross O-projection's residual read
+    // (DecGemmArgs::part) sum the eight partials in wave order instead of reading an updated h
+    const bf16_t* wo;           // [512][H*64]
+    float* opart;               // [R][H][512]
+    const float* ipart;         // [R][H][512]
 };
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream);
 

@@ -66,7 +66,10 @@ struct ymt3_ctx {
     bf16_t* mel_bf = nullptr;
     float* h_enc = nullptr;
     bf16_t *xn = nullptr, *qkv = nullptr, *attn = nullptr, *ff = nullptr, *enc_out = nullptr;
-    float* zero_bias = nullptr;         // [H][2T-1] zeros: the latent cross-attention has no position bias
+    // Perceiver-TF encoder workspace (a9): N1 = B*T*F' spectral tokens, N2 = B*T*K latent rows, D = ptf_d
+    bf16_t *p_xs = nullptr, *p_kvs = nullptr;      // [N1][D] normed spectral tokens, [N1][2D] their K/V of one block
+    float* p_z = nullptr;                          // [N2][D] fp32 latent residual stream, layout [b][t][k][:]
+    bf16_t *p_zn = nullptr, *p_qkv = nullptr, *p_att = nullptr, *p_ff = nullptr;   // [N2][D], [N2][3D], [N2][D], [N2][ptf_dff]
     // decoder workspace
     bf16_t* wkv_all = nullptr;          // [n_dec*2*inner][d]
     bf16_t* ckv = nullptr;              // [n_dec*2][B][H][T][64]
@@ -75,6 +78,7 @@ struct ymt3_ctx {
     bf16_t *dq = nullptr, *dattn = nullptr, *dff = nullptr;
     float* logits = nullptr;
     float* ssq = nullptr;               // [SSQ_TILES][maxR]
+    float* opart = nullptr;             // [maxR][H][d]: per-head O-projection partials of the self-attention kernel (fold_o)
     MoeArgs moe{};                      // scratch pointers of the MoE FFN (dec_ffn == YMT3_FFN_MOE)
     int* finished = nullptr;
     // slot mode (ymt3_transcribe_stream): per-row positions and output offsets; launch_step wires them in while set
@@ -95,6 +99,7 @@ struct ymt3_ctx {
     std::map<long, StepGraph> step_graphs;  // keyed by (B, n_chains_used, chain)
     bool use_graph = true;
     bool fuse_q = true;                     // cross-attention computes its own query projection
+    bool fold_o = true;                     // self-attention ends with its head's O-projection partial; no separate O-projection launch
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
     size_t prof_span_idx = 0;
@@ -280,13 +285,28 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->ff, BT * k.d_ff * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->enc_out, BT * d * 2)) return YMT3_ERR_HIP;
     if (k.encoder_type == YMT3_ENC_PERCEIVER_TF) {
-        if (k.n_latents != c->T) FAIL(YMT3_ERR_UNSUPPORTED, "n_latents (%d) must equal n_frames (%d) in this build", k.n_latents, c->T);
-        const size_t zb = (size_t)k.n_heads * (2 * c->T - 1) * 4;
-        if (dev_alloc(c, (void**)&c->zero_bias, zb)) return YMT3_ERR_HIP;
-        HIP_TRY(hipMemset(c->zero_bias, 0, zb));
-        const char* ptf_names[] = {"latents", "ca.ln_q", "ca.ln_kv", "ca.wq", "ca.wkv", "ca.wo", "ca.ln_ff", "ca.wi", "ca.wo2"};
-        for (const char* n : ptf_names)
-            if (!c->tensors.count(std::string("ptf.") + n)) FAIL(YMT3_ERR_BLOB, "missing ptf.%s", n);
+        const int D = k.ptf_d, K = k.n_latents;
+        if (D <= 0 || D % 64 || D > 256) FAIL(YMT3_ERR_UNSUPPORTED, "ptf_d must be 64, 128, 192 or 256 (got %d)", D);
+        if (K < 16 || K > 64 || K % 16) FAIL(YMT3_ERR_UNSUPPORTED, "n_latents must be 16, 32, 48 or 64 latents per frame (got %d)", K);
+        if (k.ptf_blocks < 1 || k.ptf_blocks > 16 || k.ptf_dff <= 0 || k.ptf_dff % 128) FAIL(YMT3_ERR_UNSUPPORTED, "ptf_blocks must be 1..16 and ptf_dff a multiple of 128");
+        if (D % 128 || (3 * D) % 128) FAIL(YMT3_ERR_UNSUPPORTED, "ptf_d must be a multiple of 128 (GEMM column tiles)");
+        if (c->T > 256 || (k.n_mels != 64 && k.n_mels != 128 && k.n_mels != 256)) FAIL(YMT3_ERR_UNSUPPORTED, "the Perceiver-TF encoder needs n_frames <= 256 and n_mels in {64, 128, 256}");
+        if (K != 32 && K != 64) FAIL(YMT3_ERR_UNSUPPORTED, "n_latents must be 32 or 64 (latent self-attention key tiles)");
+        const size_t N1 = (size_t)c->maxB * c->T * k.n_mels, N2 = (size_t)c->maxB * c->T * K;
+        if (N1 > 0x7fffffffULL / 2) FAIL(YMT3_ERR_UNSUPPORTED, "max_batch too large for the Perceiver-TF encoder workspace");
+        if (dev_alloc(c, (void**)&c->p_xs, N1 * D * 2) || dev_alloc(c, (void**)&c->p_kvs, N1 * 2 * D * 2) || dev_alloc(c, (void**)&c->p_z, N2 * D * 4) ||
+            dev_alloc(c, (void**)&c->p_zn, N2 * D * 2) || dev_alloc(c, (void**)&c->p_qkv, N2 * 3 * D * 2) || dev_alloc(c, (void**)&c->p_att, N2 * D * 2) ||
+            dev_alloc(c, (void**)&c->p_ff, N2 * k.ptf_dff * 2))
+            return YMT3_ERR_HIP;
+        std::vector<std::string> names = {"spec_w", "spec_pos", "ln_x", "latents", "bias_off", "ln_out", "out_w"};
+        for (int b = 0; b < k.ptf_blocks; ++b) {
+            const std::string p = std::to_string(b) + ".";
+            for (const char* n : {"s.ln_q", "s.wq", "s.wkv", "s.wo", "l.ln1", "l.wqkv", "l.wo", "t.ln1", "t.wqkv", "t.wo"}) names.push_back(p + n);
+            for (const char* sub : {"s.", "l.", "t."})
+                for (const char* n : {"ln_ff", "wi", "wo2"}) names.push_back(p + sub + n);
+        }
+        for (const std::string& n : names)
+            if (!c->tensors.count("ptf." + n)) FAIL(YMT3_ERR_BLOB, "missing ptf.%s", n.c_str());
     }
 
     const int nd = k.n_dec_layers;
@@ -310,6 +330,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->row_pos, R * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->row_out, R * 8)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->ssq, (size_t)SSQ_TILES * R * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->opart, R * k.n_heads * d * 4)) return YMT3_ERR_HIP;
     if (k.dec_ffn == YMT3_FFN_MOE) {
         MoeArgs& m = c->moe;
         const size_t P = 2 * R, items = P / 16 + k.n_experts + 1;
@@ -334,6 +355,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     c->use_graph = !(ng && ng[0] == '1');
     const char* nf = getenv("YMT3_NO_FUSEQ");
     c->fuse_q = !(nf && nf[0] == '1');
+    const char* nfo = getenv("YMT3_NO_FOLD_O");          // A/B: keep the separate self-attention O-projection launch
+    c->fold_o = !(nfo && nfo[0] == '1');
     const char* nc = getenv("YMT3_CHAINS");
     if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
     const char* ct = getenv("YMT3_CHAIN_THREADS");
@@ -396,8 +419,104 @@ extern "C" int ymt3_logmel(ymt3_handle h, const float* audio_dev, int B, float* 
     return YMT3_OK;
 }
 
+// a9: Perceiver-TF encoder (build-defined spec: oracle/perceiver_oracle.py).  Every FLOP is in the GEMM,
+// norm and sequence-attention kernels the T5 encoder uses; this is their orchestration over the (B, T, F', C) spectral tokens
+// and the (B, T, K, D) latent array.
+static int encode_ptf(ymt3_handle h, const float* mel, int B, bf16_t* enc_out, hipStream_t s) {
+    const ymt3_config& k = h->cfg;
+    const int T = h->T, F = k.n_mels, K = k.n_latents, D = k.ptf_d, Hs = D / 64, dff = k.ptf_dff, d = k.d_model;
+    const int N1 = B * T * F, N2 = B * T * K;
+    bf16_t *w, *lat, *pos;
+    float *f, *specw;
+    const float* tbias;
+    GET(h, "ptf.spec_w", 0u, &specw, (size_t)D);
+    GET(h, "ptf.spec_pos", 1u, &pos, (size_t)F * D);
+    GET(h, "ptf.ln_x", 0u, &f, (size_t)D);
+    LAUNCH(launch_spec_embed(mel, specw, pos, f, h->p_xs, (long long)N1, F, D, k.ln_eps, s));
+    GET(h, "ptf.latents", 1u, &lat, (size_t)K * D);
+    LAUNCH(launch_broadcast_bf16(lat, h->p_z, B * T, (size_t)K * D, s));
+    GET(h, "ptf.bias_off", 0u, const_cast<float**>(&tbias), (size_t)Hs * (2 * T - 1));
+    auto gemm = [&](int epi, const bf16_t* A, const bf16_t* Wt, void* out, int M, int N, int Kd) -> int {
+        GemmArgs g{A, Wt, out, nullptr, M, N, Kd, Kd, Kd, N, 0, 0, 0};
+        LAUNCH(launch_gemm(epi, g, s));
+        return YMT3_OK;
+    };
+    auto ffn = [&](const std::string& p) -> int {
+        GET(h, p + "ln_ff", 0u, &f, (size_t)D);
+        LAUNCH(launch_rmsnorm(h->p_z, f, h->p_zn, N2, D, k.ln_eps, s));
+        GET(h, p + "wi", 1u, &w, (size_t)dff * D);
+        int rc = gemm(EPI_BF16_RELU, h->p_zn, w, h->p_ff, N2, dff, D);
+        if (rc) return rc;
+        GET(h, p + "wo2", 1u, &w, (size_t)D * dff);
+        return gemm(EPI_RESID, h->p_ff, w, h->p_z, N2, D, dff);
+    };
+    for (int blk = 0; blk < k.ptf_blocks; ++blk) {
+        const std::string p = "ptf." + std::to_string(blk) + ".";
+        int rc;
+        // spectral cross-attention: one sequence per (segment, frame), K latent queries over the frame's F' spectral tokens
+        GET(h, p + "s.wkv", 1u, &w, (size_t)2 * D * D);
+        if ((rc = gemm(EPI_BF16, h->p_xs, w, h->p_kvs, N1, 2 * D, D))) return rc;
+        GET(h, p + "s.ln_q", 0u, &f, (size_t)D);
+        LAUNCH(launch_rmsnorm(h->p_z, f, h->p_zn, N2, D, k.ln_eps, s));
+        GET(h, p + "s.wq", 1u, &w, (size_t)D * D);
+        if ((rc = gemm(EPI_BF16, h->p_zn, w, h->p_qkv, N2, D, D))) return rc;
+        {
+            SeqAttnArgs a{};
+            a.q = h->p_qkv; a.k = h->p_kvs; a.v = h->p_kvs + D; a.out = h->p_att; a.bias_off = nullptr;
+            a.n_seq = B * T; a.H = Hs; a.Tq = K; a.Tk = F; a.inner_n = 1;
+            a.q_outer = (long long)K * D; a.q_step = D; a.kv_outer = (long long)F * 2 * D; a.kv_step = 2 * D; a.o_outer = (long long)K * D; a.o_step = D;
+            LAUNCH(launch_seq_attention(a, s));
+        }
+        GET(h, p + "s.wo", 1u, &w, (size_t)D * D);
+        if ((rc = gemm(EPI_RESID, h->p_att, w, h->p_z, N2, D, D))) return rc;
+        if ((rc = ffn(p + "s."))) return rc;
+        // latent transformer: the same sequences, self-attention among the K latents
+        GET(h, p + "l.ln1", 0u, &f, (size_t)D);
+        LAUNCH(launch_rmsnorm(h->p_z, f, h->p_zn, N2, D, k.ln_eps, s));
+        GET(h, p + "l.wqkv", 1u, &w, (size_t)3 * D * D);
+        if ((rc = gemm(EPI_BF16, h->p_zn, w, h->p_qkv, N2, 3 * D, D))) return rc;
+        {
+            SeqAttnArgs a{};
+            a.q = h->p_qkv; a.k = h->p_qkv + D; a.v = h->p_qkv + 2 * D; a.out = h->p_att; a.bias_off = nullptr;
+            a.n_seq = B * T; a.H = Hs; a.Tq = K; a.Tk = K; a.inner_n = 1;
+            a.q_outer = a.kv_outer = (long long)K * 3 * D; a.q_step = a.kv_step = 3 * D; a.o_outer = (long long)K * D; a.o_step = D;
+            LAUNCH(launch_seq_attention(a, s));
+        }
+        GET(h, p + "l.wo", 1u, &w, (size_t)D * D);
+        if ((rc = gemm(EPI_RESID, h->p_att, w, h->p_z, N2, D, D))) return rc;
+        if ((rc = ffn(p + "l."))) return rc;
+        // temporal transformer: one sequence per (segment, latent), positions = the T frames (stride K rows), T5 relative bias
+        GET(h, p + "t.ln1", 0u, &f, (size_t)D);
+        LAUNCH(launch_rmsnorm(h->p_z, f, h->p_zn, N2, D, k.ln_eps, s));
+        GET(h, p + "t.wqkv", 1u, &w, (size_t)3 * D * D);
+        if ((rc = gemm(EPI_BF16, h->p_zn, w, h->p_qkv, N2, 3 * D, D))) return rc;
+        {
+            SeqAttnArgs a{};
+            a.q = h->p_qkv; a.k = h->p_qkv + D; a.v = h->p_qkv + 2 * D; a.out = h->p_att; a.bias_off = tbias;
+            a.n_seq = B * K; a.H = Hs; a.Tq = T; a.Tk = T; a.inner_n = K;
+            a.q_outer = a.kv_outer = (long long)T * K * 3 * D; a.q_inner = a.kv_inner = 3 * D; a.q_step = a.kv_step = (long long)K * 3 * D;
+            a.o_outer = (long long)T * K * D; a.o_inner = D; a.o_step = (long long)K * D;
+            LAUNCH(launch_seq_attention(a, s));
+        }
+        GET(h, p + "t.wo", 1u, &w, (size_t)D * D);
+        if ((rc = gemm(EPI_RESID, h->p_att, w, h->p_z, N2, D, D))) return rc;
+        if ((rc = ffn(p + "t."))) return rc;
+    }
+    // (B, T, K, D) -> per-latent norm -> the K latents of a frame side by side -> d_model
+    GET(h, "ptf.ln_out", 0u, &f, (size_t)D);
+    LAUNCH(launch_rmsnorm(h->p_z, f, h->p_zn, N2, D, k.ln_eps, s));
+    GET(h, "ptf.out_w", 1u, &w, (size_t)d * K * D);
+    int rc = gemm(EPI_F32, h->p_zn, w, h->h_enc, B * T, d, K * D);
+    if (rc) return rc;
+    GET(h, "enc.ln_f", 0u, &f, (size_t)d);
+    LAUNCH(launch_rmsnorm(h->h_enc, f, enc_out, B * T, d, k.ln_eps, s));
+    HIP_TRY(hipGetLastError());
+    return YMT3_OK;
+}
+
 static int encode_impl(ymt3_handle h, const float* mel, int B, bf16_t* enc_out, hipStream_t s) {
     const ymt3_config& k = h->cfg;
+    if (k.encoder_type == YMT3_ENC_PERCEIVER_TF) return encode_ptf(h, mel, B, enc_out, s);
     const int M = B * h->T, d = k.d_model, inner = h->inner;
     LAUNCH(launch_f32_to_bf16(mel, h->mel_bf, (size_t)M * k.n_mels, s));
     bf16_t* w;
@@ -408,31 +527,6 @@ static int encode_impl(ymt3_handle h, const float* mel, int B, bf16_t* enc_out, 
         GET(h, "in_proj.b", 0u, &bias, (size_t)d);
         GemmArgs g{h->mel_bf, w, h->h_enc, bias, M, d, k.n_mels, k.n_mels, k.n_mels, d, 0, 0, 0};
         LAUNCH(launch_gemm(EPI_F32, g, s));
-    }
-    if (k.encoder_type == YMT3_ENC_PERCEIVER_TF) {
-        // a9: the learned latent array cross-attends ONCE to the projected frames (pre-norm on both sides, query
-        // residual, ReLU FFN); the enc.* blocks below then run as latent self-attention.  Oracle:
-        // oracle/perceiver_oracle.py::latent_cross_attention.
-        bf16_t* lat;
-        GET(h, "ptf.ca.ln_kv", 0u, &f, (size_t)d);
-        LAUNCH(launch_rmsnorm(h->h_enc, f, h->xn, M, d, k.ln_eps, s));
-        GET(h, "ptf.ca.wkv", 1u, &w, (size_t)2 * inner * d);
-        { GemmArgs g{h->xn, w, h->qkv, nullptr, M, 2 * inner, d, d, d, 2 * inner, 0, 0, 0}; LAUNCH(launch_gemm(EPI_BF16, g, s)); }
-        GET(h, "ptf.latents", 1u, &lat, (size_t)h->T * d);
-        LAUNCH(launch_broadcast_bf16(lat, h->h_enc, B, (size_t)h->T * d, s));      // z: the frames' stream is no longer needed
-        GET(h, "ptf.ca.ln_q", 0u, &f, (size_t)d);
-        LAUNCH(launch_rmsnorm(h->h_enc, f, h->xn, M, d, k.ln_eps, s));
-        GET(h, "ptf.ca.wq", 1u, &w, (size_t)inner * d);
-        { GemmArgs g{h->xn, w, h->attn, nullptr, M, inner, d, d, d, inner, 0, 0, 0}; LAUNCH(launch_gemm(EPI_BF16, g, s)); }
-        LAUNCH(launch_enc_attention_qkv(h->attn, inner, h->qkv, h->qkv + inner, 2 * inner, h->zero_bias, h->ff, B, h->T, k.n_heads, s));
-        GET(h, "ptf.ca.wo", 1u, &w, (size_t)d * inner);
-        { GemmArgs g{h->ff, w, h->h_enc, nullptr, M, d, inner, inner, inner, d, 0, 0, 0}; LAUNCH(launch_gemm(EPI_RESID, g, s)); }
-        GET(h, "ptf.ca.ln_ff", 0u, &f, (size_t)d);
-        LAUNCH(launch_rmsnorm(h->h_enc, f, h->xn, M, d, k.ln_eps, s));
-        GET(h, "ptf.ca.wi", 1u, &w, (size_t)k.d_ff * d);
-        { GemmArgs g{h->xn, w, h->ff, nullptr, M, k.d_ff, d, d, d, k.d_ff, 0, 0, 0}; LAUNCH(launch_gemm(EPI_BF16_RELU, g, s)); }
-        GET(h, "ptf.ca.wo2", 1u, &w, (size_t)d * k.d_ff);
-        { GemmArgs g{h->ff, w, h->h_enc, nullptr, M, d, k.d_ff, k.d_ff, k.d_ff, d, 0, 0, 0}; LAUNCH(launch_gemm(EPI_RESID, g, s)); }
     }
     const float* bias_off;
     GET(h, "enc.bias_off", 0u, const_cast<float**>(&bias_off), (size_t)k.n_heads * (2 * h->T - 1));
@@ -522,17 +616,26 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
         t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
         t.row_pos = a.row_pos;
+        const bool mc = h->fuse_q && k.n_channels >= 2 && k.n_channels <= 16 && (h->T == 128 || h->T == 256 || h->T == 512) &&
+                        row0 % k.n_channels == 0 && R % k.n_channels == 0;
+        // fold_o: the self-attention kernel leaves per-head O-projection partials; the fused cross-attention and the cross
+        // O-projection's residual read sum them (one launch less per layer, same bits).  Needs the 8-wave attention kernels
+        // and the per-row fused cross-attention
+        const bool fold = h->fold_o && h->fuse_q && !mc && H == 8 && d == 512 && R * H <= 2048;
+        if (fold) { t.wo = W.wo; t.opart = h->opart; }
         t.stamp = next_stamp(h, PC_SELF_ATTN, R * H);
         PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
+        t.wo = nullptr; t.opart = nullptr;
         a.a_bf16 = h->dattn; a.W = W.wo; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
-        a.stamp = next_stamp(h, PC_SELF_O, a.N / 16 * mtiles);
-        PLAUNCH(PC_SELF_O, launch_dec_gemm(DG_RESID, a, s));
+        if (!fold) {
+            a.stamp = next_stamp(h, PC_SELF_O, a.N / 16 * mtiles);
+            PLAUNCH(PC_SELF_O, launch_dec_gemm(DG_RESID, a, s));
+        }
         // cross-attention block: the query projection is fused into the attention kernel (YMT3_NO_FUSEQ=1 keeps
         // the separate skinny GEMM, for A/B measurements)
         t.k = h->ckv + (size_t)(2 * l) * slab; t.v = h->ckv + (size_t)(2 * l + 1) * slab; t.bias = nullptr;
         t.n_keys_const = h->T; t.slab_keys = h->T; t.rows_per_kv = k.n_channels;
-        const bool mc = h->fuse_q && k.n_channels >= 2 && k.n_channels <= 16 && (h->T == 128 || h->T == 256 || h->T == 512) &&
-                        row0 % k.n_channels == 0 && R % k.n_channels == 0;
+        if (fold) t.ipart = h->opart;
         if (mc) {
             // all channels of a segment share its K/V: one workgroup per (segment, head) serves them together
             McCrossArgs mcx{};
@@ -552,8 +655,10 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
         }
         a.a_bf16 = h->dattn; a.W = W.wo_c; a.N = d; a.K = inner;
+        a.part = fold ? h->opart : nullptr;
         a.stamp = next_stamp(h, PC_CROSS_O, a.N / 16 * mtiles);
         PLAUNCH(PC_CROSS_O, launch_dec_gemm(DG_RESID, a, s));
+        a.part = nullptr;
         // feed-forward block
         if (k.dec_ffn == YMT3_FFN_MOE) {
             MoeArgs mo = h->moe;

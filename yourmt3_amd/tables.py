@@ -95,4 +95,6 @@ def derived_tables(W: Dict[str, torch.Tensor], cfg: YMT3Config) -> Dict[str, tor
     out = frontend_tables(cfg)
     out["enc.bias_off"] = encoder_bias_table(W["enc.relbias"], cfg.n_frames, cfg)
     out["dec.bias_dist"] = decoder_bias_table(W["dec.relbias"], cfg.max_decode_len, cfg)
+    if "ptf.relbias" in W:                  # temporal transformer of the Perceiver-TF encoder: same bucket function, its own table
+        out["ptf.bias_off"] = encoder_bias_table(W["ptf.relbias"], cfg.n_frames, cfg)
     return out

@@ -127,25 +127,37 @@ def quantize_fp8_per_expert(w: torch.Tensor, n_experts: int):
 
 
 def _perceiver_weights(cfg, W, g, mat, gain):
-    """Latent-array cross-attention front of the encoder (a9; build-defined spec).
+    """Perceiver-TF encoder (a9; build-defined spec: oracle/perceiver_oracle.py)."""
+    D, K, F, dff = cfg.ptf_d, cfg.n_latents, cfg.n_mels, cfg.ptf_dff
+    H = D // 64
+    W["ptf.spec_w"] = (0.5 + 0.1 * torch.randn(D, generator=g)).float()        # log-mel values are O(10): keep x = mel*w + pos O(5)
+    W["ptf.spec_pos"] = mat(F, D, 2.0)
+    W["ptf.ln_x"] = gain(D)
+    W["ptf.latents"] = mat(K, D, 1.0)
+    W["ptf.relbias"] = (torch.randn(cfg.rel_buckets, H, generator=g) * 0.5).float()
 
-    `ptf.latents` (n_latents x d) is the learned query array; one cross-attention block (pre-norm on
-    queries and on the frame features, query residual, ReLU FFN) reads the projected frames, then the
-    `enc.*` T5 blocks run as latent self-attention."""
-    d, dff, inner = cfg.d_model, cfg.d_ff, cfg.inner
-    W["ptf.latents"] = mat(cfg.n_latents, d, 1.0)
-    W["ptf.ca.ln_q"] = gain(d)
-    W["ptf.ca.ln_kv"] = gain(d)
-    W["ptf.ca.wq"] = mat(inner, d, (d * cfg.d_kv) ** -0.5 * 4.0)
-    W["ptf.ca.wkv"] = torch.cat([mat(inner, d, d ** -0.5), mat(inner, d, d ** -0.5)], 0)
-    W["ptf.ca.wo"] = mat(d, inner, inner ** -0.5)
-    W["ptf.ca.ln_ff"] = gain(d)
-    W["ptf.ca.wi"] = mat(dff, d, d ** -0.5)
-    W["ptf.ca.wo2"] = mat(d, dff, dff ** -0.5)
+    def attn_mats():
+        return mat(D, D, (D * 64) ** -0.5 * 4.0), mat(D, D, D ** -0.5), mat(D, D, D ** -0.5), mat(D, D, D ** -0.5)
+
+    for blk in range(cfg.ptf_blocks):
+        p = f"ptf.{blk}."
+        q, k, v, o = attn_mats()
+        W[p + "s.ln_q"] = gain(D)
+        W[p + "s.wq"], W[p + "s.wkv"], W[p + "s.wo"] = q, torch.cat([k, v], 0), o
+        for sub in ("l.", "t."):
+            q, k, v, o = attn_mats()
+            W[p + sub + "ln1"] = gain(D)
+            W[p + sub + "wqkv"], W[p + sub + "wo"] = torch.cat([q, k, v], 0), o
+        for sub in ("s.", "l.", "t."):
+            W[p + sub + "ln_ff"] = gain(D)
+            W[p + sub + "wi"] = mat(dff, D, D ** -0.5)
+            W[p + sub + "wo2"] = mat(D, dff, dff ** -0.5)
+    W["ptf.ln_out"] = gain(D)
+    W["ptf.out_w"] = mat(cfg.d_model, K * D, (K * D) ** -0.5)
 
 
 _BF16_SUFFIX = ("w", "wqkv", "wo", "wi", "wo2", "wq_c", "wkv_c", "wo_c", "embed", "chan_embed",
-                "lm_head", "router", "latents", "wq", "wkv")
+                "lm_head", "router", "latents", "wq", "wkv", "spec_pos", "out_w")
 
 
 def is_bf16_tensor(name: str) -> bool:
