@@ -20,7 +20,7 @@ def throughput(cfg, B, L, reps=2):
 
 out = {
     "configs[1] T5 enc, B=64, L=1024": throughput(baseline_config(1), 64, 1024),
-    "configs[2] Perceiver latent enc, B=256, L=1024": throughput(baseline_config(2), 256, 1024),
+    "configs[2] Perceiver-TF enc (32 latents per frame, 3 blocks), B=256, L=1024": throughput(baseline_config(2), 256, 1024),
     "configs[3] 13-channel decoder, B=64, L=256": throughput(baseline_config(3), 64, 256),
     "configs[4] MoE decoder (8 experts, top-2, fp8 expert GEMMs), B=64, L=1024": throughput(baseline_config(4), 64, 1024),
     "configs[1] at B=256": throughput(baseline_config(1), 256, 1024),

@@ -326,6 +326,24 @@ def test_multichannel_beyond_128_rows():
     _check_ids("mc13_156_rows", got_t, ref_t, ref_l, got_l)
 
 
+def test_mid_tile_decode_gemms_match_oracle_at_520_rows():
+    """From 512 rows on the decode GEMMs take the mid-size tile kernel (one MFMA chain over K instead of the 8-way split):
+    40 segments x 13 channels = 520 rows, teacher-forced against the oracle with the usual tolerances; and the same rows in a
+    batch of 48 segments (624 rows, same kernels) give the same bits."""
+    cfg = YMT3Config(segment_samples=16383, max_decode_len=8, n_channels=13)        # 128 frames
+    m = _model(cfg, max_batch=48)
+    a = O.synthetic_audio(48, cfg, seed=4)
+    _, enc = O.encode(a[:40], m.weights, cfg, True)
+    n = 5
+    ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, n, True, return_logits=True)
+    e = enc.bfloat16().cuda()
+    got_t, got_l = m.decode(e, n, forced=ref_t.cuda(), return_logits=True)
+    _check_ids("mid_tile_520_rows", got_t, ref_t, ref_l, got_l)
+    e48 = torch.cat([e, m.encode(m.logmel(a[40:].cuda()))], 0)
+    assert torch.equal(m.decode(e48, n)[:40], m.decode(e, n))
+    m.close()
+
+
 @pytest.mark.parametrize("K", [13, 3, 16])
 def test_multichannel_shared_kv_cross_attention(K):
     """n_frames in {128, 256, 512} routes the multi-channel cross-attention to the one-workgroup-per-(segment, head)
@@ -415,9 +433,10 @@ def _full_size_properties(cfg, B, seed, probe, probe_len=1):
     """Size-independent properties of one BASELINE config at its full size (far beyond what the CPU oracle checks in
     seconds): shape / id range, bitwise reproducibility, independence of a segment from the rest of the batch,
     idempotence under teacher forcing with the model's own output, and a stream that has not collapsed.
-    `probe_len`: segments per independence probe.  Rows are independent inside every kernel, but the self-attention has a
-    2-wave variant for more than 2048 (row, head) pairs whose merge order differs from the 8-wave one, so a probe must stay
-    on the same side of that boundary as the full batch to be comparable bit for bit."""
+    `probe_len`: segments per independence probe.  Rows are independent inside every kernel, but two kernels have a
+    many-row form with another summation order -- the self-attention (2 waves per (row, head) beyond 2048 pairs) and the
+    decode GEMMs (mid-size tiles from 512 rows) -- so a probe must stay on the same side of those boundaries as the full
+    batch to be comparable bit for bit."""
     m = _model(cfg, max_batch=B)
     a = O.synthetic_audio(B, cfg, seed=seed).cuda()
     L = cfg.max_decode_len
@@ -470,7 +489,7 @@ def test_full_size_properties_baseline_config_2():
 def test_full_size_properties_baseline_config_3():
     """BASELINE configs[3]: 13-channel decoder, 64 segments x 13 channels = 832 rows, 256 tokens per channel."""
     from yourmt3_amd.config import baseline_config
-    m, _, t = _full_size_properties(baseline_config(3), 64, 23, (0, 17, 40), probe_len=24)     # 24 x 13 x 8 = 2496 pairs: same kernels
+    m, _, t = _full_size_properties(baseline_config(3), 64, 23, (0, 11, 24), probe_len=40)     # 40 x 13 = 520 rows: same kernels as 832
     assert not torch.equal(t[:, 0], t[:, 1])                                 # channels decode different streams
     m.close()
 

@@ -92,3 +92,40 @@ def test_hip_path_on_imported_weights_matches_hf_t5_directly():
     safe = (top2[..., 0] - top2[..., 1]) > 0.5
     assert safe.any() and torch.equal(got_t.cpu()[:, 0][safe], hf_tokens[safe].int())
     model.close()
+
+
+def test_lightning_shaped_checkpoint_container(tmp_path):
+    """the `.ckpt` container (state_dict under a key, module-path prefixes, non-tensor metadata), read with a
+    loader that executes nothing from the file; dims are checked against the config; a file the safe loader refuses is an error.
+    (No real YourMT3 checkpoint exists offline: the file is written here, in that shape, from a random HF T5.)"""
+    from yourmt3_amd.importer import from_checkpoint, load_checkpoint_tensors, find_t5_prefix
+    m = _hf()
+    direct = _imported(m)
+    sd = {"model." + k: v.clone() for k, v in m.state_dict().items()}
+    sd["model.lm_head.weight"] = m.lm_head.weight.detach().clone()
+    g = torch.Generator().manual_seed(1)
+    sd["model.pre_encoder.proj.weight"] = torch.randn(CFG.d_model, CFG.n_mels, generator=g) * 0.02
+    sd["model.pre_encoder.proj.bias"] = torch.zeros(CFG.d_model)
+    ckpt = {"state_dict": sd, "epoch": 7, "global_step": 12345, "pytorch-lightning_version": "2.1.0",
+            "hyper_parameters": {"lr": 1e-3, "task": "mt3_full"}, "optimizer_states": []}
+    path = str(tmp_path / "model.ckpt")
+    torch.save(ckpt, path)
+    assert find_t5_prefix(load_checkpoint_tensors(path)) == "model."
+    W = from_checkpoint(path, CFG, in_proj_names=("model.pre_encoder.proj.weight", "model.pre_encoder.proj.bias"))
+    assert W.keys() == direct.keys() and all(torch.equal(W[k], direct[k]) for k in W)
+    bare = str(tmp_path / "bare.pt")
+    torch.save({k[len("model."):]: v for k, v in sd.items()}, bare)             # a bare state dict, no prefix
+    W2 = from_checkpoint(bare, CFG)
+    assert torch.equal(W2["dec.3.wkv_c"], direct["dec.3.wkv_c"]) and float(W2["in_proj.w"].abs().max()) == 0.0
+    with pytest.raises(ValueError, match="d_ff"):
+        from_checkpoint(path, CFG.with_(d_ff=1024))
+    with pytest.raises(ValueError, match="no T5 encoder"):
+        torch.save({"state_dict": {"foo.weight": torch.zeros(2)}}, str(tmp_path / "x.ckpt"))
+        from_checkpoint(str(tmp_path / "x.ckpt"), CFG)
+
+    class Evil:                                                                    # a pickled class: the safe loader must refuse it
+        def __reduce__(self):
+            return (print, ("executed from the checkpoint",))
+    torch.save({"state_dict": sd, "callbacks": Evil()}, str(tmp_path / "evil.ckpt"))
+    with pytest.raises(ValueError, match="safe loader"):
+        from_checkpoint(str(tmp_path / "evil.ckpt"), CFG)

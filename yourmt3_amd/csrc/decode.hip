@@ -246,6 +246,189 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Mid-size tile form of the same GEMMs for MANY rows (R >= 256: the 13-channel decoder's 832 rows, batches of 256+).
+// The 16-row kernel above launches (R / 16) x (N / 16..32) workgroups of 143 KB LDS each -- 3328 for the FFN-in projection at
+// 832 rows, thirteen rounds over the chip -- and re-reads the weights once per 16 rows.  Here one 256-thread workgroup owns a
+// BM x 64 output tile (BM = 64, or 32 where N = 512 would leave the chip half empty), walks K in 64-wide steps through two LDS
+// stages (operands staged through registers one step ahead; the RMS norm -- row scale from the carried sum(h^2) partials,
+// gain per k -- is applied while the fp32 rows are converted), wave w owning output columns [16w, 16w + 16) of every 16-row
+// block.  Same epilogues as above (KV-cache append, ReLU, residual add + sum(h^2) partials per 16-column tile, logits).
+// K is accumulated in ONE MFMA chain per output (no 8-way split), so results differ from the 16-row kernel in the last
+// bits: the launcher switches on R alone, and rows stay independent of their batch inside either regime.
+template <int MODE, int K, int BM>
+__global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restrict__ pW, const void* __restrict__ pX, const float* __restrict__ pGain,
+                                                           float* pSsq, float* pOut, int row0, int R, int N, int ssq_stride, DecGemmArgs a) {
+    constexpr bool NORM = (MODE != DG_RESID);
+    constexpr int BN = 64, BK = 64, MT = BM / 16, PITCH = BK * 2 + 16, NKT = K / BK;
+    constexpr int A_STAGE = BM * PITCH, W_STAGE = BN * PITCH;
+    __shared__ __attribute__((aligned(16))) char sA[2][A_STAGE];
+    __shared__ __attribute__((aligned(16))) char sW[2][W_STAGE];
+    __shared__ float sscale[BM];
+    __shared__ __attribute__((aligned(16))) float sgain[NORM ? K : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int n_mt = (R + BM - 1) / BM, n_nt = N / BN;
+    int nt_idx, mt_idx;
+    if ((n_nt & 7) == 0) {                       // blocks with equal blockIdx % 8 (one XCD; speed only) walk the row tiles of one column tile
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        mt_idx = slot % n_mt;
+        nt_idx = (slot / n_mt) * 8 + xcd;
+    } else {
+        mt_idx = blockIdx.x % n_mt;
+        nt_idx = blockIdx.x / n_mt;
+    }
+    const int n0 = nt_idx * BN, m0 = row0 + mt_idx * BM, m_end = row0 + R;
+
+    // staging registers, a ring of PF K-steps: W tile 64 x 128 B = 2 x 16 B per thread; A tile BM x 128 B (bf16) or BM x 256 B (fp32).
+    // One step ahead left every step exposed to a full L2 / HBM round trip (22.6 us for K = 2048 at 832 rows, profiles/r02_notes.md)
+    constexpr int NWV = 2, NAB = BM / 32, NAF = BM / 16, PF = 4;
+    static_assert(NKT % PF == 0, "the K loop is unrolled by the prefetch depth");
+    u32x4 wvr[PF][NWV];
+    u32x4 abr[PF][NORM ? 1 : NAB];
+    f32x4 afr[PF][NORM ? NAF : 1];
+    auto load_regs = [&](int kt, u32x4 (&wv)[NWV], u32x4 (&ab)[NORM ? 1 : NAB], f32x4 (&af)[NORM ? NAF : 1]) {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+            wv[i] = *reinterpret_cast<const u32x4*>(pW + (size_t)(n0 + row) * K + kt * BK + ch * 8);
+        }
+        if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < NAF; ++i) {
+                const int idx = tid + i * 256, row = idx >> 4, ch = idx & 15;
+                int mm = m0 + row;
+                mm = mm < m_end ? mm : m_end - 1;
+                af[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(pX) + (size_t)mm * K + kt * BK + ch * 4);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NAB; ++i) {
+                const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+                int mm = m0 + row;
+                mm = mm < m_end ? mm : m_end - 1;
+                ab[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(pX) + (size_t)mm * K + kt * BK + ch * 8);
+            }
+        }
+    };
+    auto store_lds = [&](int kt, int buf, const u32x4 (&wv)[NWV], const u32x4 (&ab)[NORM ? 1 : NAB], const f32x4 (&af)[NORM ? NAF : 1]) {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+            *reinterpret_cast<u32x4*>(sW[buf] + row * PITCH + ch * 16) = wv[i];
+        }
+        if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < NAF; ++i) {
+                const int idx = tid + i * 256, row = idx >> 4, ch = idx & 15;
+                const float sc = sscale[row];
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(sgain + kt * BK + ch * 4);
+                *reinterpret_cast<uint2*>(sA[buf] + row * PITCH + ch * 8) =
+                    make_uint2(pack_bf16x2(af[i][0] * sc * gv[0], af[i][1] * sc * gv[1]), pack_bf16x2(af[i][2] * sc * gv[2], af[i][3] * sc * gv[3]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NAB; ++i) {
+                const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+                *reinterpret_cast<u32x4*>(sA[buf] + row * PITCH + ch * 16) = ab[i];
+            }
+        }
+    };
+
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_regs(p, wvr[p], abr[p], afr[p]);
+    int step = 0;
+    if constexpr (MODE == DG_NORM_QKV_CACHE) step = a.row_pos ? 0 : a.shared->step;       // per-row positions are read in the epilogue
+    if constexpr (NORM) {
+        // row scales from the carried partials (4 threads per row, 8 partials each, then the 4-lane sum) and the gain vector
+        for (int i = tid; i < K / 4; i += 256) *reinterpret_cast<f32x4*>(sgain + i * 4) = *reinterpret_cast<const f32x4*>(pGain + i * 4);
+        if (tid < BM * 4) {
+            const int row = tid >> 2;
+            const int mm = m0 + row < m_end ? m0 + row : m_end - 1;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < SSQ_TILES / 4; ++j) ss += pSsq[(size_t)((tid & 3) * (SSQ_TILES / 4) + j) * ssq_stride + mm];
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            if ((tid & 3) == 0) sscale[row] = rsqrtf(ss / (float)K + a.eps);
+        }
+        __syncthreads();
+    }
+    STAMP_IN(a);
+    store_lds(0, 0, wvr[0], abr[0], afr[0]);
+    __syncthreads();
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt0 = 0; kt0 < NKT; kt0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {             // ring slot j holds step kt0 + j; after its LDS store it is refilled with step kt + PF
+            const int kt = kt0 + j, buf = kt & 1;
+            if (kt + PF < NKT) load_regs(kt + PF, wvr[j], abr[j], afr[j]);     // slot j went to LDS one step ago (or before the loop)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW[buf] + (wave * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA[buf] + (mt * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[mt], 0, 0, 0);
+                }
+            }
+            if (kt + 1 < NKT) {
+                constexpr int PFm = PF - 1;
+                const int jn = (j + 1) & PFm;
+                // the other LDS stage: its last readers passed the barrier at the end of step kt - 1
+                if (jn == 0) store_lds(kt + 1, buf ^ 1, wvr[0], abr[0], afr[0]);
+                else if (jn == 1) store_lds(kt + 1, buf ^ 1, wvr[1], abr[1], afr[1]);
+                else if (jn == 2) store_lds(kt + 1, buf ^ 1, wvr[2], abr[2], afr[2]);
+                else store_lds(kt + 1, buf ^ 1, wvr[3], abr[3], afr[3]);
+                __syncthreads();
+            }
+        }
+    }
+
+    // epilogue: lane (li, g) of wave w holds row m0 + mt*16 + li, columns n0 + 16w + 4g .. +3
+    const int n = n0 + wave * 16 + g * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + mt * 16 + li;
+        const bool live = m < m_end;
+        f32x4 s = acc[mt];
+        if constexpr (MODE == DG_RESID) {
+            float q = 0.f;
+            if (live) {
+                float4* dst = reinterpret_cast<float4*>(pOut + (size_t)m * N + n);
+                float4 o = *dst;
+                o.x += s[0]; o.y += s[1]; o.z += s[2]; o.w += s[3];
+                *dst = o;
+                q = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+            }
+            q += __shfl_xor(q, 16, 64);           // the four lanes (g) that hold this row's 16 columns of the tile
+            q += __shfl_xor(q, 32, 64);
+            if (live && g == 0) pSsq[(size_t)(n0 / 16 + wave) * ssq_stride + m] = q;
+        } else if constexpr (MODE == DG_NORM_LOGITS) {
+            if (live) *reinterpret_cast<float4*>(pOut + (size_t)m * N + n) = make_float4(s[0], s[1], s[2], s[3]);
+        } else if (live) {
+            if constexpr (MODE == DG_NORM_BF16_RELU) { s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f); }
+            const uint2 pk = make_uint2(pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]));
+            if constexpr (MODE == DG_NORM_QKV_CACHE) {
+                const int inner = a.H * DKV;
+                if (n < inner) {
+                    *reinterpret_cast<uint2*>(a.out_bf16 + (size_t)m * inner + n) = pk;
+                } else {
+                    const int nn = n - inner, kv = nn / inner, hh = (nn % inner) >> 6, dd = nn & 63;
+                    const int pos = a.row_pos ? a.row_pos[m] : step;
+                    bf16_t* cache = kv ? a.vcache : a.kcache;
+                    *reinterpret_cast<uint2*>(cache + (((size_t)m * a.H + hh) * a.L + pos) * DKV + dd) = pk;
+                }
+            } else {
+                *reinterpret_cast<uint2*>(a.out_bf16 + (size_t)m * N + n) = pk;
+            }
+        }
+    }
+    STAMP_OUT(a);
+}
+
+// ------------------------------------------------------------------------------------------------
 // sum over the 8 lanes that share one key (lane & 7 = 16-byte chunk of the 128-byte row): DPP moves,
 // no LDS crossbar (ds_bpermute) in the inner loop
 #define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
@@ -753,9 +936,38 @@ int init_decode_kernels() {
     return rc;
 }
 
+template <int MODE, int K, int BM>
+int launch_dg_mid(const DecGemmArgs& a, hipStream_t stream) {
+    if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;
+    dec_gemm_mid_kernel<MODE, K, BM><<<(a.N / 64) * ((a.R + BM - 1) / BM), 256, 0, stream>>>(
+        a.W, MODE == DG_RESID ? static_cast<const void*>(a.a_bf16) : static_cast<const void*>(a.x_f32), a.gain, a.ssq, a.out_f32, a.row0, a.R, a.N,
+        a.ssq_stride, a);
+    return 0;
+}
+
+// many rows: the mid-size tile kernel from DEC_GEMM_MID_ROWS rows on (YMT3_DEC_GEMM_MID_ROWS overrides the threshold, 0 = never: A/B timing)
+constexpr int DEC_GEMM_MID_ROWS = 512;
+static int launch_dec_gemm_mid(int mode, const DecGemmArgs& a, hipStream_t stream) {
+    if (a.N % 64 || a.part) return -1;
+    switch (mode) {
+        case DG_RESID:
+            if (a.K == 512) return launch_dg_mid<DG_RESID, 512, 32>(a, stream);
+            if (a.K == 2048) return launch_dg_mid<DG_RESID, 2048, 32>(a, stream);
+            return -1;
+        case DG_NORM_QKV_CACHE: return a.K == 512 ? launch_dg_mid<DG_NORM_QKV_CACHE, 512, 64>(a, stream) : -1;
+        case DG_NORM_BF16: return a.K == 512 ? launch_dg_mid<DG_NORM_BF16, 512, 32>(a, stream) : -1;
+        case DG_NORM_BF16_RELU: return a.K == 512 ? launch_dg_mid<DG_NORM_BF16_RELU, 512, 64>(a, stream) : -1;
+        case DG_NORM_LOGITS: return a.K == 512 ? launch_dg_mid<DG_NORM_LOGITS, 512, 64>(a, stream) : -1;
+        default: return -1;
+    }
+}
+
 int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
     if (a.N % 16) return -1;
+    static const int mid_rows = getenv("YMT3_DEC_GEMM_MID_ROWS") ? atoi(getenv("YMT3_DEC_GEMM_MID_ROWS")) : DEC_GEMM_MID_ROWS;
+    if (mid_rows > 0 && a.R >= mid_rows && a.N % 64 == 0 && !a.part && (a.K == 512 || (a.K == 2048 && mode == DG_RESID)))
+        return launch_dec_gemm_mid(mode, a, stream);
     if (mode == DG_RESID) {
         if (a.K == 512) return launch_dg<DG_RESID, 512>(a, stream);
         if (a.K == 2048) return launch_dg<DG_RESID, 2048>(a, stream);

@@ -22,7 +22,10 @@ constexpr int XP = 520;     // xs row pitch (bf16 elements): 512 + 8
 constexpr int QP = 72;      // qs / sV row pitch (bf16 elements): 64 + 8 -> 144 bytes
 
 template <int T>
-__global__ __launch_bounds__(256) void mc_cross_attn_kernel(McCrossArgs a) {
+__global__ __launch_bounds__(256) void mc_cross_attn_kernel(const float* __restrict__ pX, const float* __restrict__ pGain, const float* __restrict__ pSsq,
+                                                            const bf16_t* __restrict__ pWq, const bf16_t* __restrict__ pK, const bf16_t* __restrict__ pV,
+                                                            int row0, int n_channels, McCrossArgs a) {
+    // leading scalar arguments: kernarg preload (see dec_gemm_kernel in decode.hip)
     constexpr int NKT = T / 64;              // 16-key tiles per wave
     constexpr int KPW = T / 4;               // keys per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(McCrossArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, seg = blockIdx.y;
-    const int nc = a.n_channels, r0 = a.row0 + seg * nc;
+    const int nc = n_channels, r0 = row0 + seg * nc;
     const size_t slab = ((size_t)seg * a.H + h) * T * DKV;
 
     // --- everything that does not depend on the projection goes in flight first: K fragments, V rows, Wq fragments
@@ -45,19 +48,19 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(McCrossArgs a) {
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            kf[kt][ks] = *reinterpret_cast<const u32x4*>(a.k + slab + (size_t)(wave * KPW + kt * 16 + li) * DKV + ks * 32 + g * 8);
+            kf[kt][ks] = *reinterpret_cast<const u32x4*>(pK + slab + (size_t)(wave * KPW + kt * 16 + li) * DKV + ks * 32 + g * 8);
 #pragma unroll
     for (int i = 0; i < KPW / 8; ++i)
-        vv[i] = *reinterpret_cast<const u32x4*>(a.v + slab + (size_t)(wave * KPW + i * 8 + (lane >> 3)) * DKV + (lane & 7) * 8);
+        vv[i] = *reinterpret_cast<const u32x4*>(pV + slab + (size_t)(wave * KPW + i * 8 + (lane >> 3)) * DKV + (lane & 7) * 8);
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-        wf[ks] = *reinterpret_cast<const u32x4*>(a.wq + ((size_t)h * DKV + wave * 16 + li) * 512 + ks * 32 + g * 8);
+        wf[ks] = *reinterpret_cast<const u32x4*>(pWq + ((size_t)h * DKV + wave * 16 + li) * 512 + ks * 32 + g * 8);
 
     // --- RMS norm of the channel rows into LDS (rows >= n_channels are zero)
     {
         const int row = tid >> 4, part = tid & 15;
         float ss = 0.f;
-        if (row < nc) ss = a.ssq[(size_t)(2 * part) * a.ssq_stride + r0 + row] + a.ssq[(size_t)(2 * part + 1) * a.ssq_stride + r0 + row];
+        if (row < nc) ss = pSsq[(size_t)(2 * part) * a.ssq_stride + r0 + row] + pSsq[(size_t)(2 * part + 1) * a.ssq_stride + r0 + row];
         ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
         if (part == 0) sscale[row] = rsqrtf(ss / 512.f + a.eps);
     }
@@ -67,8 +70,8 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(McCrossArgs a) {
         for (int i = 0; i < 2; ++i) {
             uint2 pk = make_uint2(0u, 0u);
             if (row < nc) {
-                const float4 v = reinterpret_cast<const float4*>(a.x_f32 + (size_t)(r0 + row) * 512)[lane + 64 * i];
-                const float4 gg = reinterpret_cast<const float4*>(a.gain)[lane + 64 * i];
+                const float4 v = reinterpret_cast<const float4*>(pX + (size_t)(r0 + row) * 512)[lane + 64 * i];
+                const float4 gg = reinterpret_cast<const float4*>(pGain)[lane + 64 * i];
                 const float sc = sscale[row];
                 pk = make_uint2(pack_bf16x2(v.x * sc * gg.x, v.y * sc * gg.y), pack_bf16x2(v.z * sc * gg.z, v.w * sc * gg.w));
             }
@@ -184,7 +187,7 @@ int launch_mc(const McCrossArgs& a, hipStream_t stream) {
     if (a.k == nullptr)
         return hipFuncSetAttribute(reinterpret_cast<const void*>(mc_cross_attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)mc_lds<T>()) == hipSuccess ? 0 : -2;
-    mc_cross_attn_kernel<T><<<dim3(a.H, a.n_seg), 256, mc_lds<T>(), stream>>>(a);
+    mc_cross_attn_kernel<T><<<dim3(a.H, a.n_seg), 256, mc_lds<T>(), stream>>>(a.x_f32, a.gain, a.ssq, a.wq, a.k, a.v, a.row0, a.n_channels, a);
     return 0;
 }
 

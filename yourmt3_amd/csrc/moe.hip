@@ -36,29 +36,31 @@ __device__ __forceinline__ float moe_dpp_sum8(float v) {      // sum over 8 cons
 // one wave per row.  The normed row goes through a wave-private LDS strip so that lane group e (8 lanes) can take the
 // WHOLE dot product of expert e: all E <= 8 router logits come out of one 3-step DPP reduction instead of E wave-wide
 // ones (E > 8 falls back to a second pass over experts 8..15).
-__global__ __launch_bounds__(512) void moe_router_kernel(MoeArgs a) {
+__global__ __launch_bounds__(512) void moe_router_kernel(const float* __restrict__ pH, const float* __restrict__ pGain, const float* __restrict__ pSsq,
+                                                         const bf16_t* __restrict__ pRouter, bf16_t* __restrict__ pXn, int row0, int R, int ssq_stride, int E,
+                                                         MoeArgs a) {      // leading scalars: kernarg preload (decode.hip, dec_gemm_kernel)
     __shared__ __attribute__((aligned(16))) float xrow[8][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = a.row0 + blockIdx.x * 8 + wave;
-    if (r >= a.row0 + a.R) return;
+    const int r = row0 + blockIdx.x * 8 + wave;
+    if (r >= row0 + R) return;
     constexpr int D = 512;
     float ss = 0.f;
-    if (lane < SSQ_TILES) ss = a.ssq[(size_t)lane * a.ssq_stride + r];
-    const float4* x = reinterpret_cast<const float4*>(a.h + (size_t)r * D);
-    const float4* g = reinterpret_cast<const float4*>(a.gain);
+    if (lane < SSQ_TILES) ss = pSsq[(size_t)lane * ssq_stride + r];
+    const float4* x = reinterpret_cast<const float4*>(pH + (size_t)r * D);
+    const float4* g = reinterpret_cast<const float4*>(pGain);
     const float4 v0 = x[lane], v1 = x[lane + 64], g0 = g[lane], g1 = g[lane + 64];
     // router rows for this lane's expert: lane group `grp` = expert, `sub` = which eighth of the row
     const int grp = lane >> 3, sub = lane & 7;
     uint4 wv[8];
-    const bool has_e = grp < a.E;
+    const bool has_e = grp < E;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        wv[i] = has_e ? *reinterpret_cast<const uint4*>(a.router + (size_t)grp * D + sub * 64 + i * 8) : make_uint4(0, 0, 0, 0);
+        wv[i] = has_e ? *reinterpret_cast<const uint4*>(pRouter + (size_t)grp * D + sub * 64 + i * 8) : make_uint4(0, 0, 0, 0);
     ss = wave_sum(ss);                                          // fixed-order tree over the 32 partials
     const float sc = rsqrtf(ss / (float)D + a.eps);
     auto norm4 = [&](const float4& v, const float4& gg, int idx) {
         const bf16_t b0 = f2bf(v.x * sc * gg.x), b1 = f2bf(v.y * sc * gg.y), b2 = f2bf(v.z * sc * gg.z), b3 = f2bf(v.w * sc * gg.w);
-        *reinterpret_cast<uint2*>(a.xn + (size_t)r * D + idx * 4) =
+        *reinterpret_cast<uint2*>(pXn + (size_t)r * D + idx * 4) =
             make_uint2((uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)b2 | ((uint32_t)b3 << 16));
         *reinterpret_cast<float4*>(&xrow[wave][idx * 4]) = make_float4(bf2f(b0), bf2f(b1), bf2f(b2), bf2f(b3));
     };
@@ -78,14 +80,14 @@ __global__ __launch_bounds__(512) void moe_router_kernel(MoeArgs a) {
     s = moe_dpp_sum8(s);                                        // every lane of group e now holds logit[e]
     float best = -3.4e38f, second = -3.4e38f;
     int e0 = 0, e1 = 0;
-    const int ne = a.E < 8 ? a.E : 8;
+    const int ne = E < 8 ? E : 8;
     for (int e = 0; e < ne; ++e) {
         const float le = __shfl(s, e * 8, 64);
         if (le > best) { second = best; e1 = e0; best = le; e0 = e; }
         else if (le > second) { second = le; e1 = e; }
     }
-    for (int e = 8; e < a.E; ++e) {                             // experts 8..15: plain wave-wide dots
-        const bf16_t* w = a.router + (size_t)e * D;
+    for (int e = 8; e < E; ++e) {                             // experts 8..15: plain wave-wide dots
+        const bf16_t* w = pRouter + (size_t)e * D;
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -165,7 +167,10 @@ __global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs a) {
 // STAGE 0: hidden[q] = R(relu(xn[pair_row[q]] . wi[e]^T))   (K = d_model, N = d_ff)
 // STAGE 1: y[q]      = gate[q] * (hidden[q] . wo[e]^T)      (K = d_ff,    N = d_model)
 template <int STAGE, int K>
-__global__ __launch_bounds__(512) void moe_gemm_kernel(MoeArgs a) {
+__global__ __launch_bounds__(512) void moe_gemm_kernel(const void* __restrict__ pW, const bf16_t* __restrict__ pA, const int* __restrict__ pItems,
+                                                       const int* __restrict__ pItemExpert, const int* __restrict__ pItemPair0, const int* __restrict__ pItemCount,
+                                                       const int* __restrict__ pPairRow, MoeArgs a) {
+    // leading scalars (kernarg preload): pW = this stage's expert weights (bf16 or e4m3), pA = its activation rows (xn or hidden), the work-item tables
     constexpr int KW = K / 8, KS = KW / 32, PITCH = KW * 2 + 16, STRIP = 16 * PITCH;
     constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,11 +179,11 @@ __global__ __launch_bounds__(512) void moe_gemm_kernel(MoeArgs a) {
 
     const int n_nt = (STAGE == 0 ? a.d_ff : a.d_model) / 16;
     const int item = blockIdx.x / n_nt, nt = blockIdx.x % n_nt;
-    if (item >= *a.n_items) return;
-    const int e = a.item_expert[item], q0 = a.item_pair0[item], cnt = a.item_count[item];
+    if (item >= *pItems) return;
+    const int e = pItemExpert[item], q0 = pItemPair0[item], cnt = pItemCount[item];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int n0 = nt * 16, N = STAGE == 0 ? a.d_ff : a.d_model;
-    const bf16_t* W = (STAGE == 0 ? a.wi : a.wo) + (size_t)e * N * K;
+    const bf16_t* W = static_cast<const bf16_t*>(pW) + (size_t)e * N * K;
 
     char* sA = strips + wave * 2 * STRIP;
     char* sW = sA + STRIP;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(512) void moe_gemm_kernel(MoeArgs a) {
         const int row = i * RPI + lane / LPR, ch = lane % LPR;
         wv[i] = *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + row) * K + wave * KW + ch * 8);
         const int q = q0 + (row < cnt ? row : cnt - 1);
-        const bf16_t* arow = STAGE == 0 ? a.xn + (size_t)a.pair_row[q] * K : a.hidden + (size_t)q * K;
+        const bf16_t* arow = STAGE == 0 ? pA + (size_t)pPairRow[q] * K : pA + (size_t)q * K;
         av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -231,7 +236,10 @@ __global__ __launch_bounds__(512) void moe_gemm_kernel(MoeArgs a) {
 // (per-wave partial maxima -> LDS -> 8-way max).  v_mfma_f32_16x16x32_fp8_fp8 accumulates in fp32; the epilogue
 // multiplies by row_scale * weight_scale.  Oracle: oracle/ymt3_oracle.py::moe_ffn (moe_fp8 branch).
 template <int STAGE, int K>
-__global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
+__global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(const void* __restrict__ pW, const bf16_t* __restrict__ pA, const int* __restrict__ pItems,
+                                                       const int* __restrict__ pItemExpert, const int* __restrict__ pItemPair0, const int* __restrict__ pItemCount,
+                                                       const int* __restrict__ pPairRow, MoeArgs a) {
+    // leading scalars (kernarg preload): pW = this stage's expert weights (bf16 or e4m3), pA = its activation rows (xn or hidden), the work-item tables
     constexpr int KW = K / 8, KS = KW / 32, PITCH = KW + 16, STRIP = 16 * PITCH;
     constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;          // bf16 activation rows
     constexpr int LPRW = KW / 16, RPIW = 64 / LPRW, NIW = 16 / RPIW;         // fp8 weight rows
@@ -244,13 +252,13 @@ __global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
 
     const int n_nt = (STAGE == 0 ? a.d_ff : a.d_model) / 16;
     const int item = blockIdx.x / n_nt, nt = blockIdx.x % n_nt;
-    if (item >= *a.n_items) return;
-    const int e = a.item_expert[item], q0 = a.item_pair0[item], cnt = a.item_count[item];
+    if (item >= *pItems) return;
+    const int e = pItemExpert[item], q0 = pItemPair0[item], cnt = pItemCount[item];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     if (tid < 16) smax[tid] = 0u;
     __syncthreads();
     const int n0 = nt * 16, N = STAGE == 0 ? a.d_ff : a.d_model;
-    const uint8_t* W = (STAGE == 0 ? a.wi_q8 : a.wo_q8) + (size_t)e * N * K;
+    const uint8_t* W = static_cast<const uint8_t*>(pW) + (size_t)e * N * K;
     const float wscale = (STAGE == 0 ? a.wi_s : a.wo_s)[e];
 
     char* sA = strips + wave * 2 * STRIP;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
     for (int i = 0; i < NI; ++i) {
         const int row = i * RPI + lane / LPR, ch = lane % LPR;
         const int q = q0 + (row < cnt ? row : cnt - 1);
-        const bf16_t* arow = STAGE == 0 ? a.xn + (size_t)a.pair_row[q] * K : a.hidden + (size_t)q * K;
+        const bf16_t* arow = STAGE == 0 ? pA + (size_t)pPairRow[q] * K : pA + (size_t)q * K;
         av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -337,14 +345,15 @@ __global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(MoeArgs a) {
 template <int K>
 constexpr size_t moe_fp8_lds() { return (size_t)(8 * 16 * 16 + 8 * 16 + 32) * 4 + (size_t)8 * 2 * 16 * (K / 8 + 16); }
 
-__global__ __launch_bounds__(512) void moe_combine_kernel(MoeArgs a) {
+__global__ __launch_bounds__(512) void moe_combine_kernel(float* __restrict__ pH, const float* __restrict__ pY, const int* __restrict__ pRowPair,
+                                                          float* __restrict__ pSsq, int row0, int R, int ssq_stride, MoeArgs a) {   // leading scalars: kernarg preload
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = a.row0 + blockIdx.x * 8 + wave;
-    if (r >= a.row0 + a.R) return;
+    const int r = row0 + blockIdx.x * 8 + wave;
+    if (r >= row0 + R) return;
     constexpr int D = 512;
-    const float4* y0 = reinterpret_cast<const float4*>(a.y + (size_t)a.row_pair[2 * r] * D);
-    const float4* y1 = reinterpret_cast<const float4*>(a.y + (size_t)a.row_pair[2 * r + 1] * D);
-    float4* h = reinterpret_cast<float4*>(a.h + (size_t)r * D);
+    const float4* y0 = reinterpret_cast<const float4*>(pY + (size_t)pRowPair[2 * r] * D);
+    const float4* y1 = reinterpret_cast<const float4*>(pY + (size_t)pRowPair[2 * r + 1] * D);
+    float4* h = reinterpret_cast<float4*>(pH + (size_t)r * D);
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(512) void moe_combine_kernel(MoeArgs a) {
         q += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
     }
     q = wave_sum(q);
-    if (lane < SSQ_TILES) a.ssq[(size_t)lane * a.ssq_stride + r] = lane == 0 ? q : 0.f;
+    if (lane < SSQ_TILES) pSsq[(size_t)lane * ssq_stride + r] = lane == 0 ? q : 0.f;
 }
 
 template <int STAGE, int K>
@@ -381,17 +390,17 @@ int launch_moe_stage(int stage, const MoeArgs& a, hipStream_t stream) {
     if (a.d_model != 512 || a.d_ff != 2048 || a.E > E_MAX || a.top_k != 2) return -1;
     const int max_items = (2 * a.R + 15) / 16 + a.E;
     switch (stage) {
-        case 0: moe_router_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a); break;
+        case 0: moe_router_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a.h, a.gain, a.ssq, a.router, a.xn, a.row0, a.R, a.ssq_stride, a.E, a); break;
         case 1: moe_plan_kernel<<<1, 1024, 0, stream>>>(a); break;
         case 2:
-            if (a.fp8) moe_gemm_fp8_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_fp8_lds<512>(), stream>>>(a);
-            else moe_gemm_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_lds<0, 512>(), stream>>>(a);
+            if (a.fp8) moe_gemm_fp8_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_fp8_lds<512>(), stream>>>(a.wi_q8, a.xn, a.n_items, a.item_expert, a.item_pair0, a.item_count, a.pair_row, a);
+            else moe_gemm_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_lds<0, 512>(), stream>>>(a.wi, a.xn, a.n_items, a.item_expert, a.item_pair0, a.item_count, a.pair_row, a);
             break;
         case 3:
-            if (a.fp8) moe_gemm_fp8_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_fp8_lds<2048>(), stream>>>(a);
-            else moe_gemm_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_lds<1, 2048>(), stream>>>(a);
+            if (a.fp8) moe_gemm_fp8_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_fp8_lds<2048>(), stream>>>(a.wo_q8, a.hidden, a.n_items, a.item_expert, a.item_pair0, a.item_count, a.pair_row, a);
+            else moe_gemm_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_lds<1, 2048>(), stream>>>(a.wo, a.hidden, a.n_items, a.item_expert, a.item_pair0, a.item_count, a.pair_row, a);
             break;
-        case 4: moe_combine_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a); break;
+        case 4: moe_combine_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a.h, a.y, a.row_pair, a.ssq, a.row0, a.R, a.ssq_stride, a); break;
         default: return -1;
     }
     return 0;

@@ -8,7 +8,7 @@ mapped; the audio front-end projection (`in_proj`) has no T5 counterpart and is 
 """
 from __future__ import annotations
 
-from typing import Dict, Mapping, Optional
+from typing import Dict, Mapping, Optional, Tuple
 
 import torch
 
@@ -68,3 +68,75 @@ def _check_shapes(W: Dict[str, torch.Tensor], cfg: YMT3Config) -> None:
     for k, shp in want.items():
         if tuple(W[k].shape) != shp:
             raise ValueError(f"{k}: checkpoint shape {tuple(W[k].shape)} does not match the config {shp}")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Lightning-style checkpoint containers.  Upstream trains with PyTorch Lightning (section 9,
+# UNVERIFIED), whose `.ckpt` is a pickled dict {"state_dict": {...}, "epoch": ..., "hyper_parameters": ..., ...} with
+# module-path prefixes on every tensor name.  No real checkpoint exists offline, so what is built -- and tested on
+# checkpoints written here in that shape -- is the container handling: a loader that executes nothing from the file,
+# prefix discovery, and shape checks against the config before anything reaches the blob.
+_ENC_PROBE = "encoder.block.0.layer.0.SelfAttention.q.weight"
+
+
+def load_checkpoint_tensors(path: str) -> Dict[str, torch.Tensor]:
+    """Read a `.ckpt` / `.pt` / `.safetensors` file into {name: tensor} without executing anything from it:
+    `torch.load(weights_only=True)` (refuses pickled code objects) or safetensors.  A Lightning container's
+    `state_dict` entry is unwrapped; non-tensor entries are dropped."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return dict(load_file(path))
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:                                   # pickled classes, lambdas, ...: the safe loader says no
+        raise ValueError(f"{path}: the safe loader (weights_only=True) refused this file ({type(e).__name__}: {e}); "
+                         "re-save its state_dict as plain tensors or safetensors") from e
+    if isinstance(obj, Mapping) and isinstance(obj.get("state_dict"), Mapping):
+        obj = obj["state_dict"]
+    if not isinstance(obj, Mapping):
+        raise ValueError(f"{path}: expected a state dict or a Lightning checkpoint dict, got {type(obj).__name__}")
+    return {k: v for k, v in obj.items() if isinstance(v, torch.Tensor)}
+
+
+def find_t5_prefix(names) -> str:
+    """The module path in front of the T5 stacks, e.g. 'model.' for 'model.encoder.block.0...'."""
+    hits = sorted(n[:-len(_ENC_PROBE)] for n in names if n.endswith(_ENC_PROBE))
+    if not hits:
+        raise ValueError("no T5 encoder found: no tensor name ends with '" + _ENC_PROBE + "'")
+    if len(hits) > 1:
+        raise ValueError(f"several T5 encoders in the checkpoint (prefixes {hits}); pass prefix= explicitly")
+    return hits[0]
+
+
+def infer_t5_dims(sd: Mapping[str, torch.Tensor]) -> Dict[str, int]:
+    """Transformer dims as the tensors have them (to check a config against before importing)."""
+    q = sd[_ENC_PROBE]
+    rb = sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]
+    n_enc = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.block."))
+    n_dec = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("decoder.block."))
+    return {"d_model": q.shape[1], "inner": q.shape[0], "n_heads": rb.shape[1], "rel_buckets": rb.shape[0],
+            "d_ff": sd["encoder.block.0.layer.1.DenseReluDense.wi.weight"].shape[0], "n_enc_layers": n_enc, "n_dec_layers": n_dec,
+            "vocab": sd["lm_head.weight"].shape[0]}
+
+
+def from_checkpoint(path: str, cfg: YMT3Config, prefix: Optional[str] = None,
+                    in_proj_names: Optional[Tuple[str, str]] = None) -> Dict[str, torch.Tensor]:
+    """Checkpoint file (Lightning `.ckpt`, bare state dict, safetensors) -> this build's named tensors, ready for `pack_blob`.
+
+    `prefix`: module path in front of `encoder.` / `decoder.` / `lm_head.` (discovered when None).
+    `in_proj_names`: checkpoint names of the mel -> d_model projection's (weight, bias), full names; zeros when None."""
+    raw = load_checkpoint_tensors(path)
+    pre = find_t5_prefix(raw) if prefix is None else prefix
+    sd = {k[len(pre):]: v for k, v in raw.items() if k.startswith(pre)}
+    if "lm_head.weight" not in sd:
+        raise ValueError(f"no '{pre}lm_head.weight' in the checkpoint (a tied head is not assumed: export it explicitly)")
+    dims = infer_t5_dims(sd)
+    want = {"d_model": cfg.d_model, "inner": cfg.inner, "n_heads": cfg.n_heads, "rel_buckets": cfg.rel_buckets, "d_ff": cfg.d_ff,
+            "n_enc_layers": cfg.n_enc_layers, "n_dec_layers": cfg.n_dec_layers, "vocab": cfg.vocab}
+    bad = {k: (dims[k], want[k]) for k in want if dims[k] != want[k]}
+    if bad:
+        raise ValueError("checkpoint dims differ from the config (checkpoint, config): " + ", ".join(f"{k} {v}" for k, v in bad.items()))
+    w = b = None
+    if in_proj_names is not None:
+        w, b = raw[in_proj_names[0]], raw[in_proj_names[1]]
+    return from_t5_state_dict(sd, cfg, in_proj_w=w, in_proj_b=b)
