@@ -93,7 +93,7 @@ def pmc_file(name: str):
 def pmc_traffic(cfg, B: int, L: int):
     """HBM bytes per self-attention launch from the committed rocprofv3 PMC passes (profiles/, produced by
     scripts/gpu_pmc.sh; FETCH_SIZE doubled per the gfx950 correction).  None if the profile does not match."""
-    d = pmc_file("r01_pmc_decode_attn.json")
+    d = pmc_file("r02_pmc_decode_attn.json") or pmc_file("r01_pmc_decode_attn.json")
     if d is None or B != 64 or L != 1024 or cfg.n_channels != 1:
         return None
     return d["self_attn"]["hbm_bytes_per_launch"]
@@ -114,8 +114,8 @@ def cpu_model_name() -> str:
 def cpu_baseline():
     """The oracle (a CPU *port* of this path, there being no reference implementation) on the host cores: BASELINE
     configs[0] (one segment) and a 16-segment batch, each on ONE thread and on all useful threads.
-    Each case runs the front-end + encoder fully and two bounded windows of the decode (first and last positions); the
-    full 1024 steps are the mean per-step cost of the two windows times 1024 (the cost grows linearly with the position)."""
+    The headline case (16 segments, all useful threads) is timed in full; the others run the front-end + encoder fully and two
+    bounded windows of the decode (first and last positions): mean per-step cost x 1024 (the cost grows linearly with the position)."""
     import torch
     from oracle import ymt3_oracle as O
     from yourmt3_amd.config import baseline_config
@@ -126,11 +126,12 @@ def cpu_baseline():
     # tiny per-step ops: more threads than ~16 only add fork/join overhead (128 threads ran 15x slower in round 1)
     many = min(16, n_cpu)
     L = cfg.max_decode_len
-    # (label, segments, threads, decode steps timed per window).  A decode step costs more the later it comes (the self-attention
-    # reads t cached keys and the cache append copies them), linearly in t: time a window at the first positions and one at the
-    # last positions (cache pre-filled to L - n keys) and take the mean of the two per-step costs times L
+    # (label, segments, threads, decode steps timed per window; L = the whole decode).  A decode step costs more the later it comes
+    # (the self-attention reads t cached keys and the cache append copies them), linearly in t: the bounded cases time a window at
+    # the first positions and one at the last positions (cache pre-filled to L - n keys) and take the mean per-step cost times L;
+    # the headline case (16 segments on all useful threads) runs all L steps
     cases = [("configs[0]: 1 segment", 1, 1, 48), ("configs[0]: 1 segment", 1, many, 48),
-             ("16 segments", 16, 1, 10), ("16 segments", 16, many, 48)]
+             ("16 segments", 16, 1, 10), ("16 segments", 16, many, L)]
     out = []
     for label, B, threads, n in cases:
         torch.set_num_threads(threads)
@@ -153,20 +154,27 @@ def cpu_baseline():
                 cur = torch.argmax(O.decoder_step(cur, st, ckv, W, cfg, False), dim=-1)
             return (time.perf_counter() - w0) / n
 
-        c_first, c_last = window(0), window(L - n)
-        t_dec = L * 0.5 * (c_first + c_last)
+        if n >= L:                                    # the headline case: the whole decode, nothing extrapolated
+            w0 = time.perf_counter()
+            O.greedy_decode(enc, W, cfg, L, False)
+            t_dec = time.perf_counter() - w0
+            rec = {"method": f"all {L} decode steps timed", "decode_steps_timed": L, "decode_s": round(t_dec, 2)}
+        else:
+            c_first, c_last = window(0), window(L - n)
+            t_dec = L * 0.5 * (c_first + c_last)
+            rec = {"method": f"{n} steps at the first and {n} at the last positions, mean per-step cost x {L}", "decode_steps_timed": 2 * n,
+                   "ms_per_decode_step_first": round(1e3 * c_first, 3), "ms_per_decode_step_last": round(1e3 * c_last, 3),
+                   "decode_s": round(t_dec, 2)}
         est = t_enc + t_dec
-        out.append({"workload": label, "segments": B, "threads": threads, "value": B * cfg.segment_seconds / est,
-                    "encode_s": round(t_enc, 3), "decode_steps_timed": 2 * n, "ms_per_decode_step_first": round(1e3 * c_first, 3),
-                    "ms_per_decode_step_last": round(1e3 * c_last, 3), "decode_s_extrapolated": round(t_dec, 2)})
+        out.append({"workload": label, "segments": B, "threads": threads, "value": B * cfg.segment_seconds / est, "encode_s": round(t_enc, 3), **rec})
     torch.set_num_threads(many)
     head = out[-1]
     return {
         "value": head["value"], "unit": "audio_s/wall_s", "cores": many, "kind": "port",
         "cpu_model": cpu_model_name(), "host_logical_cpus": n_cpu,
-        "sample": f"fp32 oracle (oracle/ymt3_oracle.py), 16 segments on {many} threads: front-end + encoder in full, "
-                  f"{head['decode_steps_timed'] // 2} decode steps at the first and {head['decode_steps_timed'] // 2} at the last of the {L} positions "
-                  f"timed, mean per-step cost x {L}; `variants` holds configs[0] (1 segment) and the 16-segment batch on 1 thread and on all useful threads",
+        "sample": f"fp32 oracle (oracle/ymt3_oracle.py), 16 segments on {many} threads, the whole path (front-end, encoder, all {L} decode "
+                  f"steps) timed; `variants` adds configs[0] (1 segment) on 1 and {many} threads and the 16-segment batch on 1 thread, each with "
+                  "the decode extrapolated from a window at the first and one at the last positions",
         "variants": out,
     }
 
@@ -318,7 +326,7 @@ def roofline_block(model, cfg, audio, B, L, stride, sec_per_batch) -> dict:
         "note": "top kernel by aggregate share of the decode step; bytes = rows*heads*(t+1)*64*2B*2 (K and V) averaged over sampled positions "
                 "t = stride/2, 3*stride/2, ...; duration = HIP events around each sampled launch on the launch stream minus the per-bracket "
                 "overhead calibrated against un-bracketed steps; traffic = FETCH_SIZE*2 + WRITE_SIZE per launch from "
-                "profiles/r01_pmc_decode_attn.json (separate rocprofv3 --pmc passes)",
+                "profiles/r02_pmc_decode_attn.json (separate rocprofv3 --pmc passes)",
     }
     total_bytes = decode_bytes_per_batch(cfg, B, L)
     path_gbs = total_bytes / sec_per_batch / 1e9

@@ -954,6 +954,7 @@ static int launch_dec_gemm_mid(int mode, const DecGemmArgs& a, hipStream_t strea
             if (a.K == 512) return launch_dg_mid<DG_RESID, 512, 32>(a, stream);
             if (a.K == 2048) return launch_dg_mid<DG_RESID, 2048, 32>(a, stream);
             return -1;
+        // (32-row tiles for the wide projections too: 154.6 vs 156.4 ms per configs[3] batch -- no difference; 64 stays)
         case DG_NORM_QKV_CACHE: return a.K == 512 ? launch_dg_mid<DG_NORM_QKV_CACHE, 512, 64>(a, stream) : -1;
         case DG_NORM_BF16: return a.K == 512 ? launch_dg_mid<DG_NORM_BF16, 512, 32>(a, stream) : -1;
         case DG_NORM_BF16_RELU: return a.K == 512 ? launch_dg_mid<DG_NORM_BF16_RELU, 512, 64>(a, stream) : -1;

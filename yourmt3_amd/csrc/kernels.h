@@ -201,11 +201,9 @@ struct MoeArgs {
     const float* wi_s; const float* wo_s;         // [E] dequantisation scales
     int fp8;
     bf16_t* xn;                 // [R][d_model] normed rows (bf16)
-    int* sel; float* gate;      // [R][2] chosen experts and their gates
-    int* pair_rank; int* pair_row; float* pair_gate; int* row_pair;   // [2R] pair tables (expert-sorted order q)
-    int* item_expert; int* item_pair0; int* item_count; int* n_items; // work items of <= 16 pairs
-    bf16_t* hidden;             // [2R][d_ff]
-    float* y;                   // [2R][d_model] gate-scaled expert outputs
+    int* sel; float* gate;      // [R][2] chosen experts and their gates; pair p = 2 * row + slot
+    bf16_t* hidden;             // [2R][d_ff] by pair
+    float* y;                   // [2R][d_model] gate-scaled expert outputs by pair
     int row0, R, E, top_k, d_model, d_ff;
     float eps;
 };

@@ -8,13 +8,15 @@
 //     y_j     = R( relu(xn . wi[e_j]^T) ) . wo[e_j]^T           dense ReLU FFN of expert e_j
 //     h      += g0*y_0 + g1*y_1                                 fp32, slot order fixed
 //
-// Four kernels, no float atomics, every reduction in a fixed order (bitwise reproducible):
+// Three kernels (four launches per layer), no float atomics, every reduction in a fixed order (bitwise reproducible):
 //   moe_router_kernel   one wave per row: norm from the carried sum(h^2) partials, router dots, top-2, gates
-//   moe_plan_kernel     one workgroup: stable counting sort of the 2R (row, slot) pairs by expert ->
-//                       pair tables + (expert, first pair, count) work items of <= 16 pairs
-//   moe_gemm_kernel     grouped skinny GEMM over the work items: same coalesced-load / wave-private-LDS-strip /
-//                       8-way split-K structure as dec_gemm_kernel, rows gathered through the pair table
-//   moe_combine_kernel  one wave per row: h += y[pair0] + y[pair1]; sum(h^2) for the next norm
+//   moe_gemm_kernel     grouped skinny GEMM, one workgroup per (expert, 16-column tile): it finds its expert's (row, slot)
+//                       pairs itself -- a ballot scan of the 2R selections, pairs in ascending order, chunks of <= 16, exactly
+//                       the work items a counting sort by expert would make (round 1 spent a launch on that sort) -- and walks
+//                       the chunks with its weight tile loaded ONCE: same coalesced-load / wave-private-LDS-strip / 8-way
+//                       split-K structure as dec_gemm_kernel, activation rows gathered by pair
+//   moe_combine_kernel  one wave per row: h += y[2r] + y[2r+1]; sum(h^2) for the next norm
+// Pair p = 2 * (row - row0) + slot indexes `hidden`, `y` and the gates directly: no sorted order is ever materialised.
 // Expert weights are replicated on every GPU (8 x 2 x 2 MB per layer): the path stays pure data-parallel,
 // no all-to-all.  bf16 MFMA by default; moe_fp8 = 1 selects the OCP-e4m3 MFMA form of the expert
 // GEMMs that BASELINE configs[4] names (moe_gemm_fp8_kernel below).
@@ -107,126 +109,101 @@ __global__ __launch_bounds__(512) void moe_router_kernel(const float* __restrict
     }
 }
 
-// stable counting sort of the 2R (row, slot) pairs by expert; order inside an expert: (row, slot) ascending.
-// One workgroup; ballots give every pair its rank among the same-expert pairs of its wave, a [chunk][wave][expert]
-// count table in LDS gives the rest -- two barriers per 1024 pairs, no shuffles.
-__global__ __launch_bounds__(1024) void moe_plan_kernel(MoeArgs a) {
-    __shared__ int wcnt[16][E_MAX];       // pairs of expert e in wave w of the current chunk
-    __shared__ int run[E_MAX];            // pairs of expert e in earlier chunks
-    __shared__ int off[E_MAX + 1];
+// The pairs of expert `e` among the P = 2R selections, ascending, into plist[]; returns their count (workgroup-uniform).
+// 512 threads, one pair per thread and pass; ballots give the rank inside a wave, an 8-entry LDS table the rest.
+__device__ __forceinline__ int moe_find_pairs(const int* __restrict__ sel, int P, int e, int* plist, int* wcnt) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = 2 * a.R;                                     // pairs, p = 2*(r - row0) + slot
-    if (tid < E_MAX) run[tid] = 0;
-    __syncthreads();
-    for (int base = 0; base < P; base += 1024) {
+    int total = 0;
+    for (int base = 0; base < P; base += 512) {
         const int p = base + tid;
-        const int e = p < P ? a.sel[2 * a.row0 + p] : -1;
-        int rank_in_wave = 0;
-        for (int x = 0; x < a.E; ++x) {
-            const unsigned long long m = __ballot(e == x);
-            if (e == x) rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) wcnt[wave][x] = __popcll(m);
-        }
+        const bool mine = p < P && sel[p] == e;
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) wcnt[wave] = __popcll(m);
         __syncthreads();
-        if (e >= 0) {
-            int before = run[e];
-            for (int w = 0; w < wave; ++w) before += wcnt[w][e];
-            a.pair_rank[2 * a.row0 + p] = before + rank_in_wave;
-        }
-        __syncthreads();
-        if (tid < a.E) {
-            int t = 0;
-            for (int w = 0; w < 16; ++w) t += wcnt[w][tid];
-            run[tid] += t;
-        }
+        int before = total;
+        for (int w = 0; w < wave; ++w) before += wcnt[w];
+        if (mine) plist[before + __popcll(m & ((1ull << lane) - 1ull))] = p;
+        int all = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) all += wcnt[w];
+        total += all;
         __syncthreads();
     }
-    if (tid == 0) {
-        int o = 0, items = 0;
-        for (int e = 0; e < a.E; ++e) {
-            off[e] = o;
-            for (int c = 0; c < run[e]; c += 16) {
-                a.item_expert[items] = e; a.item_pair0[items] = o + c; a.item_count[items] = min(16, run[e] - c);
-                ++items;
-            }
-            o += run[e];
-        }
-        off[a.E] = o;
-        *a.n_items = items;
-    }
-    __syncthreads();
-    for (int p = tid; p < P; p += 1024) {
-        const int e = a.sel[2 * a.row0 + p];
-        const int q = off[e] + a.pair_rank[2 * a.row0 + p];    // position in the expert-sorted order
-        a.pair_row[q] = a.row0 + (p >> 1);
-        a.pair_gate[q] = a.gate[2 * a.row0 + p];
-        a.row_pair[2 * a.row0 + p] = q;
-    }
+    return total;
 }
 
-// STAGE 0: hidden[q] = R(relu(xn[pair_row[q]] . wi[e]^T))   (K = d_model, N = d_ff)
-// STAGE 1: y[q]      = gate[q] * (hidden[q] . wo[e]^T)      (K = d_ff,    N = d_model)
+// STAGE 0: hidden[p] = R(relu(xn[row(p)] . wi[e]^T))      (K = d_model, N = d_ff)
+// STAGE 1: y[p]      = gate[p] * (hidden[p] . wo[e]^T)     (K = d_ff,    N = d_model)
 template <int STAGE, int K>
-__global__ __launch_bounds__(512) void moe_gemm_kernel(const void* __restrict__ pW, const bf16_t* __restrict__ pA, const int* __restrict__ pItems,
-                                                       const int* __restrict__ pItemExpert, const int* __restrict__ pItemPair0, const int* __restrict__ pItemCount,
-                                                       const int* __restrict__ pPairRow, MoeArgs a) {
-    // leading scalars (kernarg preload): pW = this stage's expert weights (bf16 or e4m3), pA = its activation rows (xn or hidden), the work-item tables
+__global__ __launch_bounds__(512) void moe_gemm_kernel(const void* __restrict__ pW, const bf16_t* __restrict__ pA, const int* __restrict__ pSel,
+                                                       const float* __restrict__ pGate, int row0, int R, MoeArgs a) {
+    // leading scalars (kernarg preload): pW = this stage's expert weights, pA = its activation rows (xn or hidden), the router's selections / gates
     constexpr int KW = K / 8, KS = KW / 32, PITCH = KW * 2 + 16, STRIP = 16 * PITCH;
     constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);               // [8][16][16]
-    char* strips = smem + 8 * 16 * 16 * 4;
+    int* wcnt = reinterpret_cast<int*>(red + 8 * 16 * 16);     // [8]
+    char* strips = reinterpret_cast<char*>(wcnt + 8);          // [8 waves][A strip | W strip]
+    int* plist = reinterpret_cast<int*>(strips + 8 * 2 * STRIP);   // [2R] pairs of this expert, ascending
 
-    const int n_nt = (STAGE == 0 ? a.d_ff : a.d_model) / 16;
-    const int item = blockIdx.x / n_nt, nt = blockIdx.x % n_nt;
-    if (item >= *pItems) return;
-    const int e = pItemExpert[item], q0 = pItemPair0[item], cnt = pItemCount[item];
+    const int N = STAGE == 0 ? a.d_ff : a.d_model, n_nt = N / 16;
+    const int e = blockIdx.x / n_nt, nt = blockIdx.x % n_nt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-    const int n0 = nt * 16, N = STAGE == 0 ? a.d_ff : a.d_model;
+    const int n0 = nt * 16;
     const bf16_t* W = static_cast<const bf16_t*>(pW) + (size_t)e * N * K;
 
     char* sA = strips + wave * 2 * STRIP;
     char* sW = sA + STRIP;
-    u32x4 wv[NI], av[NI];
+    u32x4 wv[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
+    for (int i = 0; i < NI; ++i) {                              // the weight tile does not depend on the routing: in flight under the scan
         const int row = i * RPI + lane / LPR, ch = lane % LPR;
         wv[i] = *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + row) * K + wave * KW + ch * 8);
-        const int q = q0 + (row < cnt ? row : cnt - 1);
-        const bf16_t* arow = STAGE == 0 ? pA + (size_t)pPairRow[q] * K : pA + (size_t)q * K;
-        av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    const int cnt_all = moe_find_pairs(pSel + 2 * row0, 2 * R, e, plist, wcnt);
+    if (cnt_all == 0) return;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int o = (i * RPI + lane / LPR) * PITCH + (lane % LPR) * 16;
-        *reinterpret_cast<u32x4*>(sW + o) = wv[i];
-        *reinterpret_cast<u32x4*>(sA + o) = av[i];
-    }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(sW + (i * RPI + lane / LPR) * PITCH + (lane % LPR) * 16) = wv[i];
+    for (int c0 = 0; c0 < cnt_all; c0 += 16) {
+        const int cnt = min(16, cnt_all - c0);
+        u32x4 av[NI];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int o = li * PITCH + (ks * 32 + g * 8) * 2;
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(sW + o),
-                                                      *reinterpret_cast<const bf16x8*>(sA + o), acc, 0, 0, 0);
-    }
-    *reinterpret_cast<float4*>(red + ((wave * 16 + li) * 16 + g * 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    __syncthreads();
-    if (tid >= 128) return;
-    const int mr = tid >> 3, nq = (tid & 7) * 2;
-    float2 s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
+        for (int i = 0; i < NI; ++i) {
+            const int row = i * RPI + lane / LPR, ch = lane % LPR;
+            const int pp = plist[c0 + (row < cnt ? row : cnt - 1)];
+            const bf16_t* arow = STAGE == 0 ? pA + (size_t)(row0 + (pp >> 1)) * K : pA + (size_t)(2 * row0 + pp) * K;
+            av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
+        }
 #pragma unroll
-    for (int w = 1; w < 8; ++w) {
-        const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * 16 + nq));
-        s.x += t.x; s.y += t.y;
-    }
-    if (mr >= cnt) return;
-    const int q = q0 + mr;
-    if constexpr (STAGE == 0) {
-        *reinterpret_cast<uint32_t*>(a.hidden + (size_t)q * a.d_ff + n0 + nq) = pack_bf16x2(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f));
-    } else {
-        const float gt = a.pair_gate[q];
-        *reinterpret_cast<float2*>(a.y + (size_t)q * a.d_model + n0 + nq) = make_float2(gt * s.x, gt * s.y);
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(sA + (i * RPI + lane / LPR) * PITCH + (lane % LPR) * 16) = av[i];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int o = li * PITCH + (ks * 32 + g * 8) * 2;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(sW + o),
+                                                          *reinterpret_cast<const bf16x8*>(sA + o), acc, 0, 0, 0);
+        }
+        *reinterpret_cast<float4*>(red + ((wave * 16 + li) * 16 + g * 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        if (tid < 128) {
+            const int mr = tid >> 3, nq = (tid & 7) * 2;
+            float2 s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * 16 + nq));
+                s.x += t.x; s.y += t.y;
+            }
+            if (mr < cnt) {
+                const int pp = 2 * row0 + plist[c0 + mr];
+                if constexpr (STAGE == 0) {
+                    *reinterpret_cast<uint32_t*>(a.hidden + (size_t)pp * a.d_ff + n0 + nq) = pack_bf16x2(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f));
+                } else {
+                    const float gt = pGate[pp];
+                    *reinterpret_cast<float2*>(a.y + (size_t)pp * a.d_model + n0 + nq) = make_float2(gt * s.x, gt * s.y);
+                }
+            }
+        }
+        __syncthreads();                                       // `red` and the activation strips are reused by the next chunk
     }
 }
 
@@ -236,123 +213,130 @@ __global__ __launch_bounds__(512) void moe_gemm_kernel(const void* __restrict__ 
 // (per-wave partial maxima -> LDS -> 8-way max).  v_mfma_f32_16x16x32_fp8_fp8 accumulates in fp32; the epilogue
 // multiplies by row_scale * weight_scale.  Oracle: oracle/ymt3_oracle.py::moe_ffn (moe_fp8 branch).
 template <int STAGE, int K>
-__global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(const void* __restrict__ pW, const bf16_t* __restrict__ pA, const int* __restrict__ pItems,
-                                                       const int* __restrict__ pItemExpert, const int* __restrict__ pItemPair0, const int* __restrict__ pItemCount,
-                                                       const int* __restrict__ pPairRow, MoeArgs a) {
-    // leading scalars (kernarg preload): pW = this stage's expert weights (bf16 or e4m3), pA = its activation rows (xn or hidden), the work-item tables
+__global__ __launch_bounds__(512) void moe_gemm_fp8_kernel(const void* __restrict__ pW, const bf16_t* __restrict__ pA, const int* __restrict__ pSel,
+                                                           const float* __restrict__ pGate, int row0, int R, MoeArgs a) {
+    // leading scalars (kernarg preload): as moe_gemm_kernel; pW = e4m3 weights
     constexpr int KW = K / 8, KS = KW / 32, PITCH = KW + 16, STRIP = 16 * PITCH;
     constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;          // bf16 activation rows
     constexpr int LPRW = KW / 16, RPIW = 64 / LPRW, NIW = 16 / RPIW;         // fp8 weight rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);               // [8][16][16]
-    unsigned* smax = reinterpret_cast<unsigned*>(red + 8 * 16 * 16);   // [16] row maxima of |x| as float bits (+ pad)
-    float* sinv = reinterpret_cast<float*>(smax) + 8 * 16;     // [16] 448 / amax
+    int* wcnt = reinterpret_cast<int*>(red + 8 * 16 * 16);     // [8]
+    unsigned* smax = reinterpret_cast<unsigned*>(wcnt + 8);    // [16] row maxima of |x| as float bits
+    float* sinv = reinterpret_cast<float*>(smax + 16);         // [16] 448 / amax
     float* sxs = sinv + 16;                                    // [16] amax / 448
     char* strips = reinterpret_cast<char*>(sxs + 16);
+    int* plist = reinterpret_cast<int*>(strips + 8 * 2 * STRIP);
 
-    const int n_nt = (STAGE == 0 ? a.d_ff : a.d_model) / 16;
-    const int item = blockIdx.x / n_nt, nt = blockIdx.x % n_nt;
-    if (item >= *pItems) return;
-    const int e = pItemExpert[item], q0 = pItemPair0[item], cnt = pItemCount[item];
+    const int N = STAGE == 0 ? a.d_ff : a.d_model, n_nt = N / 16;
+    const int e = blockIdx.x / n_nt, nt = blockIdx.x % n_nt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-    if (tid < 16) smax[tid] = 0u;
-    __syncthreads();
-    const int n0 = nt * 16, N = STAGE == 0 ? a.d_ff : a.d_model;
+    const int n0 = nt * 16;
     const uint8_t* W = static_cast<const uint8_t*>(pW) + (size_t)e * N * K;
-    const float wscale = (STAGE == 0 ? a.wi_s : a.wo_s)[e];
 
     char* sA = strips + wave * 2 * STRIP;
     char* sW = sA + STRIP;
-    u32x4 wv[NIW], av[NI];
+    u32x4 wv[NIW];
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
         const int row = i * RPIW + lane / LPRW, ch = lane % LPRW;
         wv[i] = *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + row) * K + wave * KW + ch * 16);
     }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int row = i * RPI + lane / LPR, ch = lane % LPR;
-        const int q = q0 + (row < cnt ? row : cnt - 1);
-        const bf16_t* arow = STAGE == 0 ? pA + (size_t)pPairRow[q] * K : pA + (size_t)q * K;
-        av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // row maxima of |x|: 8-lane DPP max, then one LDS integer max per (row, 8-lane group) -- |x| >= 0, so the float
-    // bit patterns order like unsigned integers
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        float mx = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] << 16)));
-            mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] & 0xffff0000u)));
-        }
-        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));
-        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));
-        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x141, 0xF, 0xF, true)));
-        if ((lane & 7) == 0) atomicMax(&smax[i * RPI + lane / LPR], __float_as_uint(mx));
-    }
+    const int cnt_all = moe_find_pairs(pSel + 2 * row0, 2 * R, e, plist, wcnt);
+    if (cnt_all == 0) return;
+    const float wscale = (STAGE == 0 ? a.wi_s : a.wo_s)[e];
 #pragma unroll
     for (int i = 0; i < NIW; ++i)
         *reinterpret_cast<u32x4*>(sW + (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16) = wv[i];
-    __syncthreads();
-    if (tid < 16) {
-        const float mx = fmaxf(__uint_as_float(smax[tid]), 1e-12f);
-        sinv[tid] = 448.0f / mx;
-        sxs[tid] = mx / 448.0f;
-    }
-    __syncthreads();
+    for (int c0 = 0; c0 < cnt_all; c0 += 16) {
+        const int cnt = min(16, cnt_all - c0);
+        if (tid < 16) smax[tid] = 0u;
+        __syncthreads();
+        u32x4 av[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int row = i * RPI + lane / LPR;
-        const float inv = sinv[row];
-        int lo = 0, hi = 0;
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][0] << 16) * inv, __uint_as_float(av[i][0] & 0xffff0000u) * inv, lo, false);
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][1] << 16) * inv, __uint_as_float(av[i][1] & 0xffff0000u) * inv, lo, true);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][2] << 16) * inv, __uint_as_float(av[i][2] & 0xffff0000u) * inv, hi, false);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][3] << 16) * inv, __uint_as_float(av[i][3] & 0xffff0000u) * inv, hi, true);
-        *reinterpret_cast<int2*>(sA + row * PITCH + (lane % LPR) * 8) = make_int2(lo, hi);
-    }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NI; ++i) {
+            const int row = i * RPI + lane / LPR, ch = lane % LPR;
+            const int pp = plist[c0 + (row < cnt ? row : cnt - 1)];
+            const bf16_t* arow = STAGE == 0 ? pA + (size_t)(row0 + (pp >> 1)) * K : pA + (size_t)(2 * row0 + pp) * K;
+            av[i] = *reinterpret_cast<const u32x4*>(arow + wave * KW + ch * 8);
+        }
+        // row maxima of |x|: 8-lane DPP max, then one LDS integer max per (row, 8-lane group) -- |x| >= 0, so the float
+        // bit patterns order like unsigned integers
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int o = li * PITCH + ks * 32 + g * 8;
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(*reinterpret_cast<const long*>(sW + o), *reinterpret_cast<const long*>(sA + o),
-                                                         acc, 0, 0, 0);
-    }
-    *reinterpret_cast<float4*>(red + ((wave * 16 + li) * 16 + g * 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    __syncthreads();
-    if (tid >= 128) return;
-    const int mr = tid >> 3, nq = (tid & 7) * 2;
-    float2 s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
+        for (int i = 0; i < NI; ++i) {
+            float mx = 0.f;
 #pragma unroll
-    for (int w = 1; w < 8; ++w) {
-        const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * 16 + nq));
-        s.x += t.x; s.y += t.y;
-    }
-    if (mr >= cnt) return;
-    const int q = q0 + mr;
-    const float sc = sxs[mr] * wscale;
-    s.x *= sc; s.y *= sc;
-    if constexpr (STAGE == 0) {
-        *reinterpret_cast<uint32_t*>(a.hidden + (size_t)q * a.d_ff + n0 + nq) = pack_bf16x2(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f));
-    } else {
-        const float gt = a.pair_gate[q];
-        *reinterpret_cast<float2*>(a.y + (size_t)q * a.d_model + n0 + nq) = make_float2(gt * s.x, gt * s.y);
+            for (int j = 0; j < 4; ++j) {
+                mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] << 16)));
+                mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] & 0xffff0000u)));
+            }
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x141, 0xF, 0xF, true)));
+            if ((lane & 7) == 0) atomicMax(&smax[i * RPI + lane / LPR], __float_as_uint(mx));
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const float mx = fmaxf(__uint_as_float(smax[tid]), 1e-12f);
+            sinv[tid] = 448.0f / mx;
+            sxs[tid] = mx / 448.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = i * RPI + lane / LPR;
+            const float inv = sinv[row];
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][0] << 16) * inv, __uint_as_float(av[i][0] & 0xffff0000u) * inv, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][1] << 16) * inv, __uint_as_float(av[i][1] & 0xffff0000u) * inv, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][2] << 16) * inv, __uint_as_float(av[i][2] & 0xffff0000u) * inv, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][3] << 16) * inv, __uint_as_float(av[i][3] & 0xffff0000u) * inv, hi, true);
+            *reinterpret_cast<int2*>(sA + row * PITCH + (lane % LPR) * 8) = make_int2(lo, hi);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int o = li * PITCH + ks * 32 + g * 8;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(*reinterpret_cast<const long*>(sW + o), *reinterpret_cast<const long*>(sA + o),
+                                                             acc, 0, 0, 0);
+        }
+        *reinterpret_cast<float4*>(red + ((wave * 16 + li) * 16 + g * 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        if (tid < 128) {
+            const int mr = tid >> 3, nq = (tid & 7) * 2;
+            float2 s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * 16 + nq));
+                s.x += t.x; s.y += t.y;
+            }
+            if (mr < cnt) {
+                const int pp = 2 * row0 + plist[c0 + mr];
+                const float sc = sxs[mr] * wscale;
+                s.x *= sc; s.y *= sc;
+                if constexpr (STAGE == 0) {
+                    *reinterpret_cast<uint32_t*>(a.hidden + (size_t)pp * a.d_ff + n0 + nq) = pack_bf16x2(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f));
+                } else {
+                    const float gt = pGate[pp];
+                    *reinterpret_cast<float2*>(a.y + (size_t)pp * a.d_model + n0 + nq) = make_float2(gt * s.x, gt * s.y);
+                }
+            }
+        }
+        __syncthreads();                                       // `red`, the row scales and the activation strips are reused by the next chunk
     }
 }
 
 template <int K>
-constexpr size_t moe_fp8_lds() { return (size_t)(8 * 16 * 16 + 8 * 16 + 32) * 4 + (size_t)8 * 2 * 16 * (K / 8 + 16); }
+constexpr size_t moe_fp8_lds(int R) { return (size_t)(8 * 16 * 16 + 8 + 48) * 4 + (size_t)8 * 2 * 16 * (K / 8 + 16) + (size_t)2 * R * 4; }
 
-__global__ __launch_bounds__(512) void moe_combine_kernel(float* __restrict__ pH, const float* __restrict__ pY, const int* __restrict__ pRowPair,
-                                                          float* __restrict__ pSsq, int row0, int R, int ssq_stride, MoeArgs a) {   // leading scalars: kernarg preload
+__global__ __launch_bounds__(512) void moe_combine_kernel(float* __restrict__ pH, const float* __restrict__ pY, float* __restrict__ pSsq, int row0,
+                                                          int R, int ssq_stride, MoeArgs a) {   // leading scalars: kernarg preload
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = row0 + blockIdx.x * 8 + wave;
     if (r >= row0 + R) return;
     constexpr int D = 512;
-    const float4* y0 = reinterpret_cast<const float4*>(pY + (size_t)pRowPair[2 * r] * D);
-    const float4* y1 = reinterpret_cast<const float4*>(pY + (size_t)pRowPair[2 * r + 1] * D);
+    const float4* y0 = reinterpret_cast<const float4*>(pY + (size_t)(2 * r) * D);
+    const float4* y1 = reinterpret_cast<const float4*>(pY + (size_t)(2 * r + 1) * D);
     float4* h = reinterpret_cast<float4*>(pH + (size_t)r * D);
     float q = 0.f;
 #pragma unroll
@@ -368,39 +352,39 @@ __global__ __launch_bounds__(512) void moe_combine_kernel(float* __restrict__ pH
 }
 
 template <int STAGE, int K>
-constexpr size_t moe_lds() { return (size_t)8 * 16 * 16 * 4 + (size_t)8 * 2 * 16 * (K / 8 * 2 + 16); }
+constexpr size_t moe_lds(int R) { return (size_t)(8 * 16 * 16 + 8) * 4 + (size_t)8 * 2 * 16 * (K / 8 * 2 + 16) + (size_t)2 * R * 4; }
 
 }  // namespace
 
+constexpr int MOE_MAX_ROWS = 1536;       // LDS pair list: 2 * rows * 4 B on top of the 135 KB of strips of the K = 2048 stage (160 KB per CU)
+
 int init_moe_kernels() {
     const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_kernel<0, 512>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_lds<0, 512>());
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_lds<0, 512>(MOE_MAX_ROWS));
     const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_kernel<1, 2048>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_lds<1, 2048>());
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_lds<1, 2048>(MOE_MAX_ROWS));
     const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_fp8_kernel<0, 512>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_fp8_lds<512>());
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_fp8_lds<512>(MOE_MAX_ROWS));
     const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_fp8_kernel<1, 2048>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_fp8_lds<2048>());
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)moe_fp8_lds<2048>(MOE_MAX_ROWS));
     return (e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -2;
 }
 
-// stage: 0 router, 1 plan, 2 expert wi, 3 expert wo, 4 combine
+// stage: 0 router, 1 expert wi, 2 expert wo, 3 combine
 int launch_moe_stage(int stage, const MoeArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
-    if (a.d_model != 512 || a.d_ff != 2048 || a.E > E_MAX || a.top_k != 2) return -1;
-    const int max_items = (2 * a.R + 15) / 16 + a.E;
+    if (a.d_model != 512 || a.d_ff != 2048 || a.E > E_MAX || a.top_k != 2 || a.R > MOE_MAX_ROWS) return -1;
     switch (stage) {
         case 0: moe_router_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a.h, a.gain, a.ssq, a.router, a.xn, a.row0, a.R, a.ssq_stride, a.E, a); break;
-        case 1: moe_plan_kernel<<<1, 1024, 0, stream>>>(a); break;
+        case 1:
+            if (a.fp8) moe_gemm_fp8_kernel<0, 512><<<a.E * (a.d_ff / 16), 512, moe_fp8_lds<512>(a.R), stream>>>(a.wi_q8, a.xn, a.sel, a.gate, a.row0, a.R, a);
+            else moe_gemm_kernel<0, 512><<<a.E * (a.d_ff / 16), 512, moe_lds<0, 512>(a.R), stream>>>(a.wi, a.xn, a.sel, a.gate, a.row0, a.R, a);
+            break;
         case 2:
-            if (a.fp8) moe_gemm_fp8_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_fp8_lds<512>(), stream>>>(a.wi_q8, a.xn, a.n_items, a.item_expert, a.item_pair0, a.item_count, a.pair_row, a);
-            else moe_gemm_kernel<0, 512><<<max_items * (a.d_ff / 16), 512, moe_lds<0, 512>(), stream>>>(a.wi, a.xn, a.n_items, a.item_expert, a.item_pair0, a.item_count, a.pair_row, a);
+            if (a.fp8) moe_gemm_fp8_kernel<1, 2048><<<a.E * (a.d_model / 16), 512, moe_fp8_lds<2048>(a.R), stream>>>(a.wo_q8, a.hidden, a.sel, a.gate, a.row0, a.R, a);
+            else moe_gemm_kernel<1, 2048><<<a.E * (a.d_model / 16), 512, moe_lds<1, 2048>(a.R), stream>>>(a.wo, a.hidden, a.sel, a.gate, a.row0, a.R, a);
             break;
-        case 3:
-            if (a.fp8) moe_gemm_fp8_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_fp8_lds<2048>(), stream>>>(a.wo_q8, a.hidden, a.n_items, a.item_expert, a.item_pair0, a.item_count, a.pair_row, a);
-            else moe_gemm_kernel<1, 2048><<<max_items * (a.d_model / 16), 512, moe_lds<1, 2048>(), stream>>>(a.wo, a.hidden, a.n_items, a.item_expert, a.item_pair0, a.item_count, a.pair_row, a);
-            break;
-        case 4: moe_combine_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a.h, a.y, a.row_pair, a.ssq, a.row0, a.R, a.ssq_stride, a); break;
+        case 3: moe_combine_kernel<<<(a.R + 7) / 8, 512, 0, stream>>>(a.h, a.y, a.ssq, a.row0, a.R, a.ssq_stride, a); break;
         default: return -1;
     }
     return 0;

@@ -333,12 +333,10 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->opart, R * k.n_heads * d * 4)) return YMT3_ERR_HIP;
     if (k.dec_ffn == YMT3_FFN_MOE) {
         MoeArgs& m = c->moe;
-        const size_t P = 2 * R, items = P / 16 + k.n_experts + 1;
+        const size_t P = 2 * R;
+        if (R > 1536) FAIL(YMT3_ERR_UNSUPPORTED, "the MoE FFN holds its pair list in LDS: at most 1536 decoder rows (got %zu)", R);
         if (dev_alloc(c, (void**)&m.xn, R * d * 2) || dev_alloc(c, (void**)&m.sel, P * 4) || dev_alloc(c, (void**)&m.gate, P * 4) ||
-            dev_alloc(c, (void**)&m.pair_rank, P * 4) || dev_alloc(c, (void**)&m.pair_row, P * 4) || dev_alloc(c, (void**)&m.pair_gate, P * 4) ||
-            dev_alloc(c, (void**)&m.row_pair, P * 4) || dev_alloc(c, (void**)&m.item_expert, items * 4) ||
-            dev_alloc(c, (void**)&m.item_pair0, items * 4) || dev_alloc(c, (void**)&m.item_count, items * 4) ||
-            dev_alloc(c, (void**)&m.n_items, 16) || dev_alloc(c, (void**)&m.hidden, P * k.d_ff * 2) || dev_alloc(c, (void**)&m.y, P * d * 4))
+            dev_alloc(c, (void**)&m.hidden, P * k.d_ff * 2) || dev_alloc(c, (void**)&m.y, P * d * 4))
             return YMT3_ERR_HIP;
         m.E = k.n_experts; m.top_k = k.moe_top_k; m.d_model = d; m.d_ff = k.d_ff; m.eps = k.ln_eps;
     }
@@ -665,8 +663,8 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             mo.h = h->h_dec; mo.gain = W.ln3; mo.ssq = h->ssq; mo.ssq_stride = h->maxR;
             mo.router = W.router; mo.wi = W.wi; mo.wo = W.wo2; mo.row0 = row0; mo.R = R;
             mo.wi_q8 = W.wi_q8; mo.wo_q8 = W.wo_q8; mo.wi_s = W.wi_s; mo.wo_s = W.wo_s; mo.fp8 = k.moe_fp8;
-            { ProfScope _ps(h, PC_FFN_WI, s); LAUNCH(launch_moe_stage(0, mo, s)); LAUNCH(launch_moe_stage(1, mo, s)); LAUNCH(launch_moe_stage(2, mo, s)); }
-            { ProfScope _ps(h, PC_FFN_WO, s); LAUNCH(launch_moe_stage(3, mo, s)); LAUNCH(launch_moe_stage(4, mo, s)); }
+            { ProfScope _ps(h, PC_FFN_WI, s); LAUNCH(launch_moe_stage(0, mo, s)); LAUNCH(launch_moe_stage(1, mo, s)); }
+            { ProfScope _ps(h, PC_FFN_WO, s); LAUNCH(launch_moe_stage(2, mo, s)); LAUNCH(launch_moe_stage(3, mo, s)); }
         } else {
             a.gain = W.ln3; a.W = W.wi; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
             a.stamp = next_stamp(h, PC_FFN_WI, a.N / 16 * mtiles);
