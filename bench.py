@@ -256,6 +256,7 @@ def run(args):
         print(json.dumps(result), flush=True)
     model.close()
     if world > 1:
+        torch.distributed.barrier()             # rank 0 profiles after the timed region: leave the group together
         torch.distributed.destroy_process_group()
 
 

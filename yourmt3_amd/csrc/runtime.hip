@@ -88,10 +88,11 @@ struct ymt3_ctx {
     bool slot_mode = false;
     DecodeShared* shared = nullptr;     // [MAX_CHAINS] per-chain loop state
     hipStream_t cap_stream = nullptr;
-    // Decode rows are independent, so a batch CAN be cut into `n_chains` contiguous row ranges whose
-    // step graphs replay concurrently on separate HIP streams.  Measured on MI355X (profiles/r01_notes.md):
-    // it loses -- every hipGraphLaunch of the ~50-node step costs ~150 us of host time, so 2/4/8 chains
-    // ran 372/653/937 ms per batch against 351 ms for one chain.  Default 1; YMT3_CHAINS overrides.
+    // Decode rows are independent, so a batch CAN be cut into `n_chains` contiguous row ranges whose step graphs replay
+    // concurrently on separate HIP streams.  Measured on MI355X in both rounds (profiles/r01_chain_sweep.txt with one host thread
+    // feeding all chains, profiles/r02_chain_sweep_threads.txt with one launcher thread per chain): it loses -- 2 chains 289.8 ms
+    // per batch against 279.8 for one, 3 / 4 chains 474 / 486 ms -- so the chains do not overlap on the device either.
+    // Default 1; YMT3_CHAINS overrides (kept as a tested option: any row split must give identical ids).
     int n_chains = 1;
     bool chain_threads = true;              // one launcher thread per chain (YMT3_CHAIN_THREADS=0: the caller's thread feeds all)
     hipStream_t chain_stream[8] = {};
