@@ -33,6 +33,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="segments per GPU (BASELINE configs[1]: 64)")
     ap.add_argument("--decode-len", type=int, default=0, help="override L (0 = config's 1024); non-default runs are not the headline metric")
+    ap.add_argument("--frames", type=int, default=256, choices=(256, 512),
+                    help="encoder frames per segment: 256 = the 2.048 s headline shape; 512 = BASELINE configs[1]'s '512-frame encoder' wording (4.096 s segments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=32)
@@ -94,7 +96,7 @@ def pmc_traffic(cfg, B: int, L: int):
     """HBM bytes per self-attention launch from the committed rocprofv3 PMC passes (profiles/, produced by
     scripts/gpu_pmc.sh; FETCH_SIZE doubled per the gfx950 correction).  None if the profile does not match."""
     d = pmc_file("r02_pmc_decode_attn.json") or pmc_file("r01_pmc_decode_attn.json")
-    if d is None or B != 64 or L != 1024 or cfg.n_channels != 1:
+    if d is None or B != 64 or L != 1024 or cfg.n_channels != 1 or cfg.n_frames != 256:
         return None
     return d["self_attn"]["hbm_bytes_per_launch"]
 
@@ -191,6 +193,8 @@ def run(args):
     dev = torch.device("cuda", local_rank)
 
     cfg = baseline_config(1)
+    if args.frames == 512:
+        cfg = cfg.with_(segment_samples=65535)
     L = args.decode_len or cfg.max_decode_len
     B = args.batch
     model = YourMT3(cfg, seed=1234, device=local_rank, max_batch=B)
@@ -239,7 +243,7 @@ def run(args):
         "p50_batch_latency_ms": 1e3 * statistics.median(lat),
         "config": {
             "workload": "BASELINE configs[1]: MT3 base (T5-small dims, 6+6 layers, d512, 8x64 heads, d_ff 2048, vocab 1536), "
-                        "2.048 s / 16 kHz / 128-mel segments (256 encoder frames), greedy decode forced to "
+                        f"{cfg.segment_seconds:.3f} s / 16 kHz / 128-mel segments ({cfg.n_frames} encoder frames), greedy decode forced to "
                         f"{L} tokens, seeded random weights",
             "segments_per_gpu": B, "global_batch": B * world, "decode_len": L, "frames": cfg.n_frames,
             "parallelism": f"dp{world} (segments sharded, token ids all-gathered over RCCL)",

@@ -24,5 +24,6 @@ out = {
     "configs[3] 13-channel decoder, B=64, L=256": throughput(baseline_config(3), 64, 256),
     "configs[4] MoE decoder (8 experts, top-2, fp8 expert GEMMs), B=64, L=1024": throughput(baseline_config(4), 64, 1024),
     "configs[1] at B=256": throughput(baseline_config(1), 256, 1024),
+    "configs[1] with 512-frame segments (4.096 s), B=64, L=1024": throughput(baseline_config(1).with_(segment_samples=65535), 64, 1024),
 }
 print(json.dumps(out, indent=1))
