@@ -620,7 +620,9 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         // fold_o: the self-attention kernel leaves per-head O-projection partials; the fused cross-attention and the cross
         // O-projection's residual read sum them (one launch less per layer, same bits).  Needs the 8-wave attention kernels
         // and the per-row fused cross-attention
-        const bool fold = h->fold_o && h->fuse_q && !mc && H == 8 && d == 512 && R * H <= 2048;
+        // and pays only while the per-(row, head) pull of wo (64 KB each) stays small against the launch it removes: +0.3 % at 64 rows,
+        // -1.4 % at 128, -3.5 % at 256 (profiles/r02_b256_fold_fuseq_variants.txt); same bits either way
+        const bool fold = h->fold_o && h->fuse_q && !mc && H == 8 && d == 512 && R <= 96;
         if (fold) { t.wo = W.wo; t.opart = h->opart; }
         t.stamp = next_stamp(h, PC_SELF_ATTN, R * H);
         PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
