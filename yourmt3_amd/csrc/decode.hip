@@ -37,6 +37,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // Measurement only (YMT3_STAMP=1 at ymt3_create; the pointer is null otherwise): constant-rate wall clock (100 MHz) at the
 // first instruction of a workgroup and at the end of its last wave, read back by ymt3_debug_step_stamps to split a decode
 // step into launch gaps, dispatch ramps and kernel bodies.
+#ifndef YMT3_STAMP_PHASE
+#define YMT3_STAMP_PHASE 0           // 1 / 2: timing-only builds that move dec_gemm_kernel's entry stamp to a later phase (tools, not product)
+#endif
 #define STAMP_IN(a) do { if ((a).stamp && threadIdx.x == 0) (a).stamp[2 * blockIdx.x] = wall_clock64(); } while (0)
 #define STAMP_OUT(a) do { if ((a).stamp && (threadIdx.x & 63) == 0) atomicMax((a).stamp + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64()); } while (0)
 
@@ -190,12 +193,18 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
         }
     }
 
+#if YMT3_STAMP_PHASE == 1
+    STAMP_IN(a);             // timing-only build: "entry" = operands have arrived and the MFMAs are done
+#endif
     // fixed-order cross-wave reduction: red[wave][row][n (COLS)]
 #pragma unroll
     for (int c = 0; c < NT; ++c)
         *reinterpret_cast<float4*>(red + ((wave * ROWS + li) * COLS + c * 16 + g * 4)) =
             make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
     __syncthreads();
+#if YMT3_STAMP_PHASE == 2
+    STAMP_IN(a);             // timing-only build: "entry" = partial tiles reduced across waves, epilogue next
+#endif
     float2 s = make_float2(0.f, 0.f);
     if (epi) {
         s = *reinterpret_cast<const float2*>(red + (mr * COLS + nq));
