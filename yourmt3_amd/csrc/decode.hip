@@ -4,7 +4,7 @@
 // hipGraph of a step can be replayed for every position with no host round trip (SURVEY section 3.4:
 // the per-step `.max()==0` host sync of TP: generation/utils.py:2936-2937 becomes device state).
 //
-//  dec_gemm_kernel      skinny GEMM, R = segments x channels rows (64..832) against a [N][K] bf16
+//  dec_gemm_kernel      skinny GEMM, R = segments x channels rows (up to 511) against a [N][K] bf16
 //                       weight: one workgroup per 16 rows x 16 output columns, eight waves split K, each
 //                       wave pulls its K-slice of both operands with whole-line coalesced loads (all in
 //                       flight at once), parks them in a wave-private LDS strip and reads MFMA fragments
@@ -12,10 +12,12 @@
 //                       no float atomics).  NORM modes apply the T5 RMS norm (TP: modeling_t5.py:50-72)
 //                       with the row's sum(h^2) carried between kernels as partials; the epilogues fuse
 //                       KV-cache append (TP: cache_utils.py:144-145), ReLU, residual add + sum(h^2) partials.
+//  dec_gemm_mid_kernel  the same GEMMs on BM x 64 tiles with a K loop, from 512 rows on (the 13-channel decoder).
 //  dec_attn_kernel      one (row, head) per workgroup; K/V slabs streamed HBM -> registers with 16-byte
 //                       coalesced loads, 8-12 in flight per lane; online softmax per 8-lane group (DPP sums),
 //                       merged by shuffles and one LDS pass.  Self-attention adds the unidirectional relative
-//                       position bias by distance (TP: modeling_t5.py:264-279); cross-attention has none and
+//                       position bias by distance (TP: modeling_t5.py:264-279) and, up to 96 rows, ends with its
+//                       head's share of the output projection (OP); cross-attention has no bias and
 //                       computes its own query projection (FUSEQ) while its K/V loads are in flight.
 //  argmax_embed_kernel  fp32 argmax (first index wins ties, TP: utils.py:2925), EOS -> PAD fill
 //                       (:2928-2929), token store, next-token embedding gather into the residual
@@ -455,8 +457,10 @@ __device__ __forceinline__ float sum8(float v) {
 // NW = waves per (row, head): 8 for up to ~2k workgroups (16 waves per CU keep > 12 MB in flight chip-wide); 2 when there
 // are many more (row, head) pairs than CUs (multi-channel / large batches), where 512-thread workgroups with a few keys
 // each only add dispatch rounds.
-// (Two rows per workgroup sharing the head's projection weights -- half the weight reads from L2 -- was measured and is
-// slower: 10.2 vs 8.7 us, eight waves per CU keep too little of the K/V stream in flight; profiles/r01_step_stamps.txt.)
+// (Two rows per workgroup sharing the head's projection weights -- half the weight reads from L2 -- was measured twice and is
+// slower: with 512 threads, 10.2 vs 8.7 us, eight waves per CU keep too little of the K/V stream in flight
+// (profiles/r01_step_stamps.txt); with 1024 threads, one workgroup per CU puts both rows' projections and streams in lockstep behind
+// the same barriers, +1.4 us per cross-attention launch, and the folded self-attention gains nothing end to end (profiles/r02_two_rows*.txt).)
 // OP (O-projection partials; 8 waves only).  SELF: the kernel ends with its head's share of the output projection,
 // opart[r][h][:] = R(o) . wo[:, 64h..64h+64)^T -- the same two chained MFMAs over the same 64 k as wave h of the DG_RESID kernel, so
 // the values are that kernel's split-K partials bit for bit; the 64 weight rows x 128 B of every wave come in by LDS DMA issued
