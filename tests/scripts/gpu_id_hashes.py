@@ -33,8 +33,22 @@ CASES = {
 }
 
 
-def digest(cfg, B, L, seed):
-    m = YourMT3(cfg, make_weights(cfg, seed=1234), device=0, max_batch=B)
+# the MoE cases pin the round-1 sums, which include the combine launch's own sum(h^2) tree: the round-2 default folds the combine
+# into the next norm GEMM (another tree, same tolerance against the oracle), so these cases run with the launch kept
+ENV = {"moe_bf16_t64_b3_l32": {"YMT3_MOE_COMBINE_LAUNCH": "1"}, "moe_fp8_t64_b3_l32": {"YMT3_MOE_COMBINE_LAUNCH": "1"}}
+
+
+def digest(cfg, B, L, seed, env=None):
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        m = YourMT3(cfg, make_weights(cfg, seed=1234), device=0, max_batch=B)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     a = O.synthetic_audio(B, cfg, seed=seed).cuda()
     t = m.inference(a, max_token_length=L).cpu().contiguous()
     m.close()
@@ -47,7 +61,7 @@ def main():
     for name, (cfg, B, L, seed) in CASES.items():
         if only and name not in only:
             continue
-        got[name] = digest(cfg, B, L, seed)
+        got[name] = digest(cfg, B, L, seed, ENV.get(name))
         print(name, got[name], flush=True)
     if "--write" in sys.argv:
         os.makedirs("gpurun_out", exist_ok=True)

@@ -65,7 +65,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // NT = 16-column tiles per workgroup (1 or 2): two halve the workgroup count of the wide projections (QKV, FFN-in, lm_head)
 // to about one per CU -- at two per CU the second one's operands queue behind the first's and the kernel's last exit came
 // 1.1 us after its first (profiles/r01_step_stamps.txt) -- and the activation strip is read once for both.
-template <int MODE, int K, int NT>
+// PEND (NORM modes, MoE decoder): the residual stream still lacks the previous layer's expert outputs -- x = h + (y[2r] + y[2r+1]),
+// the sum the MoE combine launch used to store.  The kernel forms x while loading, takes sum(x^2) itself (16-lane row sums, then
+// the eight waves in order), and the workgroups of column tile 0 write x to a.h_out, the OTHER residual buffer (the rest of the
+// layer reads that one; writing in place would race with the other column tiles still reading h): one launch less per MoE layer.
+template <int MODE, int K, int NT, bool PEND = false>
 __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict__ pW, const void* __restrict__ pX, const float* __restrict__ pGain,
                                                        float* pSsq, float* pOut, int row0, int R, int N, int ssq_stride, DecGemmArgs a) {
     // The operand pointers and the tile geometry are LEADING SCALAR kernel arguments (14 dwords): built with
@@ -78,10 +82,12 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
     constexpr int PITCH = KW * 2 + 16;   // bytes per strip row (bf16 slice + 16 B pad against bank conflicts)
     constexpr int STRIP = 16 * PITCH;    // one operand strip (16 rows) of one wave
     static_assert(MODE != DG_RESID || NT == 1, "the RESID epilogue writes one sum(h^2) partial per 16-column tile");
+    static_assert(!PEND || NORM, "a pending combine is folded into the norm prologue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);                    // [8][ROWS][COLS]
     float* sscale = red + 8 * ROWS * COLS;                          // [ROWS]
-    char* strips = smem + (8 * ROWS * COLS + ROWS) * 4;             // [8 waves][A strip | NT W strips]
+    float* wpart = sscale + ROWS;                                   // PEND: [8 waves][ROWS] sum(x^2) of each wave's K-slice
+    char* strips = smem + (8 * ROWS * COLS + ROWS + (PEND ? 8 * ROWS : 0)) * 4;   // [8 waves][A strip | NT W strips]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -141,22 +147,60 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
                 xv[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(pX) + (size_t)mm * K + wave * KW + (lane % LPRX) * 4);
             }
             const f32x4 gv = *reinterpret_cast<const f32x4*>(pGain + wave * KW + (lane % LPRX) * 4);
+            f32x4 y0v[PEND ? NIX : 1], y1v[PEND ? NIX : 1];
             float ss = 0.f;
-            if (tid < ROWS * 8) {                                    // 8 threads per row, 4 of the 32 partials each
+            if constexpr (PEND) {
+#pragma unroll
+                for (int i = 0; i < NIX; ++i) {
+                    int mm = m0 + i * RPIX + lane / LPRX;
+                    mm = mm < m_end ? mm : m_end - 1;
+                    const float* yr = a.pend_y + (size_t)(2 * mm) * K + wave * KW + (lane % LPRX) * 4;
+                    y0v[i] = *reinterpret_cast<const f32x4*>(yr);
+                    y1v[i] = *reinterpret_cast<const f32x4*>(yr + K);
+                }
+            } else if (tid < ROWS * 8) {                             // 8 threads per row, 4 of the 32 partials each
                 const int mm = m0 + (tid >> 3) < m_end ? m0 + (tid >> 3) : m_end - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ss += pSsq[(size_t)((tid & 7) * 4 + j) * ssq_stride + mm];
             }
             __builtin_amdgcn_sched_barrier(0);   // every operand load is in flight before anything waits
             STAMP_IN(a);                         // (reads a.stamp from the kernarg segment: after the loads, not in front of them)
-            ss += __shfl_xor(ss, 1, 64);
-            ss += __shfl_xor(ss, 2, 64);
-            ss += __shfl_xor(ss, 4, 64);
-            if (tid < ROWS * 8 && (tid & 7) == 0) sscale[tid >> 3] = rsqrtf(ss / (float)K + a.eps);
+            if constexpr (PEND) {
+#pragma unroll
+                for (int i = 0; i < NIX; ++i) {
+                    const int row = i * RPIX + lane / LPRX;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[i][e] += y0v[i][e] + y1v[i][e];          // h + (y0 + y1), as the combine kernel summed
+                    float q = (xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1]) + (xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3]);
+                    q += __shfl_xor(q, 1, 64);                       // the LPRX = 16 lanes that hold this row's K-slice
+                    q += __shfl_xor(q, 2, 64);
+                    q += __shfl_xor(q, 4, 64);
+                    q += __shfl_xor(q, 8, 64);
+                    if ((lane % LPRX) == 0) wpart[wave * ROWS + row] = q;
+                    if constexpr (MODE == DG_NORM_QKV_CACHE) {       // (lm_head is the last reader of the stream: nothing to publish)
+                        if (nt_idx == 0 && m0 + row < m_end)         // column tile 0 publishes the completed residual row
+                            *reinterpret_cast<f32x4*>(a.h_out + (size_t)(m0 + row) * K + wave * KW + (lane % LPRX) * 4) = xv[i];
+                    }
+                }
+            } else {
+                ss += __shfl_xor(ss, 1, 64);
+                ss += __shfl_xor(ss, 2, 64);
+                ss += __shfl_xor(ss, 4, 64);
+                if (tid < ROWS * 8 && (tid & 7) == 0) sscale[tid >> 3] = rsqrtf(ss / (float)K + a.eps);
+            }
 #pragma unroll
             for (int i = 0; i < NIW; ++i)
                 *reinterpret_cast<u32x4*>(sW + (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16) = wv[i];
             __syncthreads();
+            if constexpr (PEND) {
+                if (tid < ROWS) {
+                    float t = wpart[tid];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) t += wpart[w * ROWS + tid];
+                    sscale[tid] = rsqrtf(t / (float)K + a.eps);
+                }
+                __syncthreads();
+            }
 #pragma unroll
             for (int i = 0; i < NIX; ++i) {
                 const int row = i * RPIX + lane / LPRX;
@@ -902,30 +946,31 @@ __global__ void pad_tail_kernel(int32_t* tokens_out, int row0, int n_steps, int 
     for (int i = from + threadIdx.x; i < n_steps; i += blockDim.x) row[i] = pad_id;
 }
 
-template <int MODE, int K, int NT>
+template <int MODE, int K, int NT, bool PEND = false>
 constexpr size_t dg_lds_bytes() {
-    return (size_t)(8 * 16 * 16 * NT + 16) * 4 + (size_t)8 * (1 + NT) * 16 * (K / 8 * 2 + 16);
+    return (size_t)(8 * 16 * 16 * NT + 16 + (PEND ? 8 * 16 : 0)) * 4 + (size_t)8 * (1 + NT) * 16 * (K / 8 * 2 + 16);
 }
 
-template <int MODE, int K, int NT = 1>
+template <int MODE, int K, int NT = 1, bool PEND = false>
 int launch_dg(const DecGemmArgs& a, hipStream_t stream) {
     if (a.W == nullptr)     // attribute-only call from init_decode_kernels(): > 64 KB of dynamic LDS needs opting in
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, NT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K, NT>()) == hipSuccess ? 0 : -2;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<MODE, K, NT, PEND>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dg_lds_bytes<MODE, K, NT, PEND>()) == hipSuccess ? 0 : -2;
     if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;   // the norm consumers sum exactly SSQ_TILES partials
-    dec_gemm_kernel<MODE, K, NT><<<(a.N / (16 * NT)) * ((a.R + 15) / 16), 512, dg_lds_bytes<MODE, K, NT>(), stream>>>(
+    if (PEND && (!a.pend_y || (MODE == DG_NORM_QKV_CACHE && !a.h_out))) return -4;
+    dec_gemm_kernel<MODE, K, NT, PEND><<<(a.N / (16 * NT)) * ((a.R + 15) / 16), 512, dg_lds_bytes<MODE, K, NT, PEND>(), stream>>>(
         a.W, MODE == DG_RESID ? static_cast<const void*>(a.a_bf16) : static_cast<const void*>(a.x_f32), a.gain, a.ssq, a.out_f32, a.row0, a.R, a.N,
         a.ssq_stride, a);
     return 0;
 }
 
 // wide projections: 32 columns per workgroup once 16-column tiles would put more than one workgroup on a CU
-template <int MODE>
+template <int MODE, bool PEND = false>
 int launch_dg_wide(const DecGemmArgs& a, hipStream_t stream) {
     static const bool narrow = getenv("YMT3_DEC_GEMM_NARROW") != nullptr;      // A/B timing only
     const int wgs16 = (a.N / 16) * ((a.R + 15) / 16);
-    if (!narrow && a.N % 32 == 0 && wgs16 > 320) return launch_dg<MODE, 512, 2>(a, stream);
-    return launch_dg<MODE, 512, 1>(a, stream);
+    if (!narrow && a.N % 32 == 0 && wgs16 > 320) return launch_dg<MODE, 512, 2, PEND>(a, stream);
+    return launch_dg<MODE, 512, 1, PEND>(a, stream);
 }
 
 }  // namespace
@@ -944,6 +989,10 @@ int init_decode_kernels() {
     rc |= launch_dg<DG_NORM_BF16, 512, 2>(z, nullptr);
     rc |= launch_dg<DG_NORM_BF16_RELU, 512, 2>(z, nullptr);
     rc |= launch_dg<DG_NORM_LOGITS, 512, 2>(z, nullptr);
+    rc |= launch_dg<DG_NORM_QKV_CACHE, 512, 1, true>(z, nullptr);
+    rc |= launch_dg<DG_NORM_QKV_CACHE, 512, 2, true>(z, nullptr);
+    rc |= launch_dg<DG_NORM_LOGITS, 512, 1, true>(z, nullptr);
+    rc |= launch_dg<DG_NORM_LOGITS, 512, 2, true>(z, nullptr);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             WO_LDS_BYTES) != hipSuccess) rc |= -2;
     return rc;
@@ -980,7 +1029,7 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
     if (a.N % 16) return -1;
     static const int mid_rows = getenv("YMT3_DEC_GEMM_MID_ROWS") ? atoi(getenv("YMT3_DEC_GEMM_MID_ROWS")) : DEC_GEMM_MID_ROWS;
-    if (mid_rows > 0 && a.R >= mid_rows && a.N % 64 == 0 && !a.part && (a.K == 512 || (a.K == 2048 && mode == DG_RESID)))
+    if (mid_rows > 0 && a.R >= mid_rows && a.N % 64 == 0 && !a.part && !a.pend_y && (a.K == 512 || (a.K == 2048 && mode == DG_RESID)))
         return launch_dec_gemm_mid(mode, a, stream);
     if (mode == DG_RESID) {
         if (a.K == 512) return launch_dg<DG_RESID, 512>(a, stream);
@@ -989,6 +1038,11 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
         return -1;
     }
     if (a.K != 512) return -1;
+    if (a.pend_y) {           // a pending MoE combine: only the two kernels that can follow an MoE FFN take it
+        if (mode == DG_NORM_QKV_CACHE) return launch_dg_wide<DG_NORM_QKV_CACHE, true>(a, stream);
+        if (mode == DG_NORM_LOGITS) return launch_dg_wide<DG_NORM_LOGITS, true>(a, stream);
+        return -1;
+    }
     switch (mode) {
         case DG_NORM_QKV_CACHE: return launch_dg_wide<DG_NORM_QKV_CACHE>(a, stream);
         case DG_NORM_BF16: return launch_dg_wide<DG_NORM_BF16>(a, stream);

@@ -112,6 +112,10 @@ struct DecGemmArgs {
     // MODE_RESID only, or null: per-head O-projection partials [R][H][N] left by the self-attention kernel; the residual
     // operand becomes h + (p0 + p1 + ... + p7) -- the sum the separate O-projection launch would have stored in h
     const float* part;
+    // NORM modes after an MoE FFN whose combine launch was folded away, or null: y [2R][K] gate-scaled expert outputs by pair;
+    // the residual row is x_f32 + (y[2r] + y[2r+1]) and the workgroups of column tile 0 store it to h_out (QKV mode)
+    const float* pend_y;
+    float* h_out;
 };
 enum DecGemmMode { DG_NORM_QKV_CACHE = 0, DG_NORM_BF16 = 1, DG_NORM_BF16_RELU = 2, DG_NORM_LOGITS = 3, DG_RESID = 4 };
 int init_decode_kernels();

@@ -75,6 +75,7 @@ struct ymt3_ctx {
     bf16_t* ckv = nullptr;              // [n_dec*2][B][H][T][64]
     bf16_t *kcache = nullptr, *vcache = nullptr;   // [n_dec][maxR][H][L][64]
     float* h_dec = nullptr;
+    float* h_dec2 = nullptr;            // MoE decoder: the second residual buffer of the folded combine (layers alternate between the two)
     bf16_t *dq = nullptr, *dattn = nullptr, *dff = nullptr;
     float* logits = nullptr;
     float* ssq = nullptr;               // [SSQ_TILES][maxR]
@@ -100,6 +101,7 @@ struct ymt3_ctx {
     std::map<long, StepGraph> step_graphs;  // keyed by (B, n_chains_used, chain)
     bool use_graph = true;
     bool fuse_q = true;                     // cross-attention computes its own query projection
+    bool moe_fold_combine = true;           // MoE: h += y0 + y1 is done by the next norm GEMM's prologue (YMT3_MOE_COMBINE_LAUNCH=1: own launch)
     bool fold_o = true;                     // self-attention ends with its head's O-projection partial; no separate O-projection launch
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
@@ -323,6 +325,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->kcache, cache_elems * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->vcache, cache_elems * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->h_dec, R * d * 4)) return YMT3_ERR_HIP;
+    if (k.dec_ffn == YMT3_FFN_MOE && dev_alloc(c, (void**)&c->h_dec2, R * d * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->dq, R * c->inner * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->dattn, R * c->inner * 2)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->dff, R * k.d_ff * 2)) return YMT3_ERR_HIP;
@@ -354,6 +357,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     c->use_graph = !(ng && ng[0] == '1');
     const char* nf = getenv("YMT3_NO_FUSEQ");
     c->fuse_q = !(nf && nf[0] == '1');
+    const char* mcl = getenv("YMT3_MOE_COMBINE_LAUNCH");
+    c->moe_fold_combine = !(mcl && mcl[0] == '1');
     const char* nfo = getenv("YMT3_NO_FOLD_O");          // A/B: keep the separate self-attention O-projection launch
     c->fold_o = !(nfo && nfo[0] == '1');
     const char* nc = getenv("YMT3_CHAINS");
@@ -601,16 +606,27 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     (void)w;
     h->stamp_n = 0;
     const int mtiles = (R + 15) / 16;
+    // MoE with the combine folded away: after an MoE FFN the residual stream is hcur + (y[2r] + y[2r+1]) until the next norm GEMM
+    // (the next layer's QKV projection, or lm_head) has formed it; that QKV kernel stores it to the other buffer, which the rest of
+    // its layer then uses.  Needs the 16-row decode GEMMs (below the mid-size tile threshold).
+    const bool fold_combine = k.dec_ffn == YMT3_FFN_MOE && h->moe_fold_combine && R < 512;
+    float* hcur = h->h_dec;
+    const float* pend = nullptr;
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const LayerW& W = LW[l];
         DecGemmArgs a{};
         a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
         a.row_pos = h->slot_mode ? h->row_pos : nullptr;
         // self-attention block
-        a.x_f32 = h->h_dec; a.gain = W.ln1; a.W = W.wqkv; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
+        a.x_f32 = hcur; a.gain = W.ln1; a.W = W.wqkv; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
+        if (pend) {                                  // the previous layer's expert outputs are still to be added: x -> the other buffer
+            a.pend_y = pend;
+            a.h_out = hcur == h->h_dec ? h->h_dec2 : h->h_dec;
+        }
         a.kcache = h->kcache + l * layer_cache; a.vcache = h->vcache + l * layer_cache;
         a.stamp = next_stamp(h, PC_QKV, a.N / 16 * mtiles);
         PLAUNCH(PC_QKV, launch_dec_gemm(DG_NORM_QKV_CACHE, a, s));
+        if (pend) { hcur = a.h_out; pend = nullptr; a.pend_y = nullptr; a.h_out = nullptr; }
         DecAttnArgs t{};
         t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
         t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
@@ -627,7 +643,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         t.stamp = next_stamp(h, PC_SELF_ATTN, R * H);
         PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
         t.wo = nullptr; t.opart = nullptr;
-        a.a_bf16 = h->dattn; a.W = W.wo; a.N = d; a.K = inner; a.out_f32 = h->h_dec;
+        a.a_bf16 = h->dattn; a.W = W.wo; a.N = d; a.K = inner; a.out_f32 = hcur;
         if (!fold) {
             a.stamp = next_stamp(h, PC_SELF_O, a.N / 16 * mtiles);
             PLAUNCH(PC_SELF_O, launch_dec_gemm(DG_RESID, a, s));
@@ -640,12 +656,12 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         if (mc) {
             // all channels of a segment share its K/V: one workgroup per (segment, head) serves them together
             McCrossArgs mcx{};
-            mcx.x_f32 = h->h_dec; mcx.gain = W.ln2; mcx.ssq = h->ssq; mcx.ssq_stride = h->maxR; mcx.eps = k.ln_eps;
+            mcx.x_f32 = hcur; mcx.gain = W.ln2; mcx.ssq = h->ssq; mcx.ssq_stride = h->maxR; mcx.eps = k.ln_eps;
             mcx.wq = W.wq_c; mcx.k = t.k + (size_t)(row0 / k.n_channels) * H * h->T * 64; mcx.v = t.v + (size_t)(row0 / k.n_channels) * H * h->T * 64;
             mcx.out = h->dattn; mcx.row0 = row0; mcx.n_seg = R / k.n_channels; mcx.n_channels = k.n_channels; mcx.H = H; mcx.T = h->T;
             PLAUNCH(PC_CROSS_ATTN, launch_mc_cross_attention(mcx, s));
         } else if (h->fuse_q) {
-            t.wq = W.wq_c; t.x_f32 = h->h_dec; t.gain = W.ln2; t.ssq = h->ssq; t.ssq_stride = h->maxR; t.eps = k.ln_eps;
+            t.wq = W.wq_c; t.x_f32 = hcur; t.gain = W.ln2; t.ssq = h->ssq; t.ssq_stride = h->maxR; t.eps = k.ln_eps;
         } else {
             a.gain = W.ln2; a.W = W.wq_c; a.N = inner; a.K = d; a.out_bf16 = h->dq;
             a.stamp = next_stamp(h, PC_CROSS_Q, a.N / 16 * mtiles);
@@ -663,11 +679,12 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         // feed-forward block
         if (k.dec_ffn == YMT3_FFN_MOE) {
             MoeArgs mo = h->moe;
-            mo.h = h->h_dec; mo.gain = W.ln3; mo.ssq = h->ssq; mo.ssq_stride = h->maxR;
+            mo.h = hcur; mo.gain = W.ln3; mo.ssq = h->ssq; mo.ssq_stride = h->maxR;
             mo.router = W.router; mo.wi = W.wi; mo.wo = W.wo2; mo.row0 = row0; mo.R = R;
             mo.wi_q8 = W.wi_q8; mo.wo_q8 = W.wo_q8; mo.wi_s = W.wi_s; mo.wo_s = W.wo_s; mo.fp8 = k.moe_fp8;
             { ProfScope _ps(h, PC_FFN_WI, s); LAUNCH(launch_moe_stage(0, mo, s)); LAUNCH(launch_moe_stage(1, mo, s)); }
-            { ProfScope _ps(h, PC_FFN_WO, s); LAUNCH(launch_moe_stage(2, mo, s)); LAUNCH(launch_moe_stage(3, mo, s)); }
+            { ProfScope _ps(h, PC_FFN_WO, s); LAUNCH(launch_moe_stage(2, mo, s)); if (!fold_combine) LAUNCH(launch_moe_stage(3, mo, s)); }
+            if (fold_combine) pend = mo.y;
         } else {
             a.gain = W.ln3; a.W = W.wi; a.N = k.d_ff; a.K = d; a.out_bf16 = h->dff;
             a.stamp = next_stamp(h, PC_FFN_WI, a.N / 16 * mtiles);
@@ -680,7 +697,8 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     DecGemmArgs a{};
     a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
     GET(h, "dec.ln_f", 0u, &f, (size_t)d);
-    a.x_f32 = h->h_dec; a.gain = f; a.W = lm_head; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
+    a.x_f32 = hcur; a.gain = f; a.W = lm_head; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
+    a.pend_y = pend;                                 // the last layer's expert outputs, if their combine was folded away
     a.stamp = next_stamp(h, PC_LM_HEAD, a.N / 16 * mtiles);
     PLAUNCH(PC_LM_HEAD, launch_dec_gemm(DG_NORM_LOGITS, a, s));
     ArgmaxArgs g{};
