@@ -341,15 +341,18 @@ def roofline_block(model, cfg, audio, B, L, stride, sec_per_batch) -> dict:
         "note": "whole hot path: (decoder weights + cross K/V per step + self K/V cache at each position, summed over the decode) / "
                 "measured seconds per batch (graph replay, the timed region above); front-end and encoder (MFMA-bound, < 1 % of a batch) add no bytes here",
     }
-    gemm_names = [k for k in kern if k.endswith("_gemm")]
+    gemm_names = [k for k in kern if k.endswith("_gemm") or k == "gemm_chain"]
     gemm_us = sum(us[k] * per_step[k] for k in gemm_names)
     gemm_bytes = sum(wb.get(k, 0) * per_step[k] for k in gemm_names)
+    if "gemm_chain" in kern:       # one launch = cross O + FFN-in + FFN-out + the next layer's QKV projection (lm_head after the last layer)
+        n_chain = per_step["gemm_chain"]
+        gemm_bytes += n_chain * (wb["cross_o_gemm"] + wb["ffn_wi_gemm"] + wb["ffn_wo_gemm"]) + (n_chain - 1) * wb["qkv_cache_gemm"] + wb["lm_head_gemm"]
     out["roofline_kernels"] = {
         "cross_attn": hbm(ca_bytes + (wb["cross_q"] if "cross_q_gemm" not in kern else 0), "cross_attn") if "cross_attn" in kern else None,
         "dec_gemm_family": {"share_of_step": gemm_us / step_us, "launches_per_step": sum(per_step[k] for k in gemm_names),
                             "weight_bytes_per_step": gemm_bytes, "achieved": gemm_bytes / (gemm_us * 1e-6) / 1e9,
                             "frac": gemm_bytes / (gemm_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
-                            "note": "latency-bound skinny GEMMs (64 rows): weight bytes / time, against the HBM peak"},
+                            "note": "latency-bound skinny GEMMs (64 rows; a gemm_chain launch holds four of them): weight bytes / time, against the HBM peak"},
         "launches_per_step": launches_per_step,
     }
     out["decode_step_breakdown_us"] = {k: round(us[k] * per_step[k], 2) for k in kern}

@@ -628,11 +628,36 @@ def test_folded_o_projection_is_bit_identical_to_the_separate_launch(small, monk
     old.close()
 
 
+def test_gemm_chain_is_bit_identical_to_the_four_launches(small, monkeypatch):
+    """Round 2: cross O-projection -> FFN-in -> FFN-out -> next QKV projection (or lm_head) run as ONE launch whose stages hand
+    16-row tiles to each other through arrival counters and agent-scope loads / stores (dec_chain.hip).  Same K-slices, MFMA chains
+    and reduction orders as dec_gemm_kernel: logits and ids must not move by one bit against YMT3_NO_GEMM_CHAIN=1, for full and
+    ragged row tiles, lock-step and slot mode."""
+    monkeypatch.setenv("YMT3_NO_GEMM_CHAIN", "1")
+    old = _model(SMALL, max_batch=40)
+    monkeypatch.delenv("YMT3_NO_GEMM_CHAIN")
+    new = _model(SMALL, max_batch=40)
+    for B in (1, 4, 21, 40):
+        a = O.synthetic_audio(B, SMALL, seed=30 + B).cuda()
+        e = new.encode(new.logmel(a))
+        t_new, l_new = new.decode(e, 48, return_logits=True)
+        t_old, l_old = old.decode(e, 48, return_logits=True)
+        assert torch.equal(t_new, t_old) and torch.equal(l_new, l_old), B
+        assert int(t_new.min()) >= 0
+    a = O.synthetic_audio(9, SMALL, seed=77).cuda()
+    assert torch.equal(new.inference_stream(a, slots=5, interval=4), old.inference_stream(a, slots=5, interval=4))
+    new.close()
+    old.close()
+
+
 def test_profile_hooks(small):
     e = small.encode(small.logmel(O.synthetic_audio(2, SMALL).cuda()))
     prof = small.profile_decode(e, 32, stride=8)
     assert prof["self_attn"]["launches"] == 4 * SMALL.n_dec_layers and prof["self_attn"]["ms_total"] > 0
-    assert prof["lm_head_gemm"]["launches"] == 4 and prof["unsampled_span"]["launches"] == 3
+    # the last layer's GEMM-chain launch ends with lm_head (dec_chain.hip): one chain launch per layer, no lm_head launch of its own
+    assert prof["gemm_chain"]["launches"] == 4 * SMALL.n_dec_layers and prof["lm_head_gemm"]["launches"] == 0
+    assert prof["qkv_cache_gemm"]["launches"] == 4 and prof["ffn_wi_gemm"]["launches"] == 0
+    assert prof["unsampled_span"]["launches"] == 3
 
 
 def test_decode_start_debug_hook_is_gated_and_one_shot(small, monkeypatch):
@@ -672,8 +697,8 @@ def test_step_stamps_hook(small, monkeypatch):
     plain = small.inference(a.cuda(), max_token_length=8)
     assert torch.equal(m.inference(a.cuda(), max_token_length=8), plain)       # stamping changes no result
     rows = m.step_stamps()
-    assert len(rows) == 6 * 6 + 2 and rows[0][0] == "qkv_cache_gemm" and rows[-1][0] == "argmax_embed"     # 38 launches per step
-    assert [r[0] for r in rows[:6]] == ["qkv_cache_gemm", "self_attn", "cross_attn", "cross_o_gemm", "ffn_wi_gemm", "ffn_wo_gemm"]
+    assert len(rows) == 1 + 3 * 6 + 1 and rows[0][0] == "qkv_cache_gemm" and rows[-1][0] == "argmax_embed"  # 20 launches per step
+    assert [r[0] for r in rows[:5]] == ["qkv_cache_gemm", "self_attn", "cross_attn", "gemm_chain", "self_attn"]
     prev_exit = 0.0
     for name, grid, in0, in1, out0, out1 in rows:
         assert grid > 0 and in0 <= in1 and in0 <= out0 <= out1, (name, in0, in1, out0, out1)

@@ -789,6 +789,9 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __re
             for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(dst + c * 16) = make_float4(pa[c][0], pa[c][1], pa[c][2], pa[c][3]);
         }
     }
+    if constexpr (FUSEQ) {
+        if (a.chain_sync && blockIdx.x == 0 && tid < CHAIN_COUNTERS) a.chain_sync[tid * CHAIN_LINE] = 0u;      // the next launch's arrival counters (dec_chain.hip)
+    }
     STAMP_OUT(a);
 }
 
@@ -1055,6 +1058,7 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
     const bool many = a.R * a.H > 2048;
+    if (a.chain_sync && (self_attn || !a.wq)) return -1;                              // only the fused cross-attention zeroes the chain counters
     if ((a.wo || a.ipart) && (many || a.H != 8 || (a.wo && !a.opart) || (a.ipart && !a.wq))) return -1;   // folded O-projection: 8 heads, 8-wave kernels
     if (a.row0 < 0 || a.row0 > 0xffff || a.rows_per_kv < 1 || a.rows_per_kv > 0xff || a.H < 1 || a.H > 0xff || a.slab_keys < 1 || a.slab_keys > 0xfffff ||
         a.n_keys_const < 0 || a.n_keys_const > 0xfff || (self_attn && a.bias_stride != a.slab_keys))

@@ -117,6 +117,37 @@ struct DecGemmArgs {
     const float* pend_y;
     float* h_out;
 };
+// The four skinny GEMMs between a layer's cross-attention and the next layer's self-attention as one launch (dec_chain.hip):
+// cross O-projection -> FFN-in -> FFN-out -> next QKV projection (or lm_head); dense FFN, d_model = 512, d_ff = 2048, R <= 64.
+struct ChainArgs {
+    const bf16_t *w0, *w1, *w2, *w3;   // wo_c [512][512], wi [d_ff][512], wo2 [512][d_ff], next wqkv [3*512][512] or lm_head [V][512]
+    const bf16_t* attn;         // [R][512] cross-attention output
+    const float* part;          // folded self-attention O-projection partials [R][8][512], or null (DecGemmArgs::part)
+    float* h;                   // [R][512] residual stream (read, += twice)
+    float* ssq; int ssq_stride; // sum(h^2) partials, as DecGemmArgs
+    const float *gain1, *gain3; // ln3 of this layer; ln1 of the next layer or ln_f
+    bf16_t* dff;                // [R][d_ff] FFN hidden (scratch)
+    int d_ff;
+    int mode3, N3;              // DG_NORM_QKV_CACHE (N3 = 3*512) or DG_NORM_LOGITS (N3 = vocab)
+    bf16_t* out_q; bf16_t* kcache; bf16_t* vcache;   // stage 3, QKV mode (next layer's cache slabs)
+    float* logits;              // stage 3, lm_head mode
+    int H, L;
+    const DecodeShared* shared; const int* row_pos;
+    int row0, R;
+    float eps;
+    unsigned* sync;             // CHAIN_SYNC_WORDS: arrival counters [3 boundaries][4 row tiles][8 replicas], one 128-byte line each (zeroed by the
+                                // preceding cross-attention launch), then the sticky abort word on a line of its own
+    unsigned* host_abort;       // pinned host word, set with the abort (the host refuses further calls)
+    unsigned long long* stamp;
+};
+constexpr int CHAIN_LINE = 32;                                  // 32-bit words per 128-byte line
+constexpr int CHAIN_COUNTERS = 3 * 4 * 8;
+constexpr int CHAIN_ABORT_WORD = CHAIN_COUNTERS * CHAIN_LINE;
+constexpr int CHAIN_SYNC_WORDS = (CHAIN_COUNTERS + 1) * CHAIN_LINE;
+int init_chain_kernels();
+int launch_dec_chain(const ChainArgs& c, hipStream_t stream);       // 0 launched, < 0: not this kernel's shape
+int launch_chain_poison(const unsigned* sync, int32_t* tokens, long long n, hipStream_t stream);   // tokens = INT32_MIN if the chain aborted
+
 enum DecGemmMode { DG_NORM_QKV_CACHE = 0, DG_NORM_BF16 = 1, DG_NORM_BF16_RELU = 2, DG_NORM_LOGITS = 3, DG_RESID = 4 };
 int init_decode_kernels();
 int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream);
@@ -147,6 +178,7 @@ struct DecAttnArgs {
     const bf16_t* wo;           // [512][H*64]
     float* opart;               // [R][H][512]
     const float* ipart;         // [R][H][512]
+    unsigned* chain_sync;       // fused cross-attention, or null: the arrival counters of the GEMM chain launched next (dec_chain.hip), zeroed here
 };
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream);
 

@@ -103,6 +103,10 @@ struct ymt3_ctx {
     bool fuse_q = true;                     // cross-attention computes its own query projection
     bool moe_fold_combine = true;           // MoE: h += y0 + y1 is done by the next norm GEMM's prologue (YMT3_MOE_COMBINE_LAUNCH=1: own launch)
     bool fold_o = true;                     // self-attention ends with its head's O-projection partial; no separate O-projection launch
+    bool gemm_chain = true;                 // cross O -> FFN-in -> FFN-out -> next QKV / lm_head as one launch (dec_chain.hip; YMT3_NO_GEMM_CHAIN=1: four launches)
+    unsigned* chain_sync = nullptr;         // [CHAIN_SYNC_WORDS] device: the chain kernel's arrival counters + sticky abort word
+    unsigned* chain_host_abort = nullptr;   // pinned: set by the chain kernel together with the abort word; checked at every call
+    bool chain_used = false;                // the last captured / launched step contains chain launches
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
     size_t prof_span_idx = 0;
@@ -131,7 +135,7 @@ static unsigned long long* next_stamp(ymt3_ctx* c, int cls, int grid) {
     return c->stamp_buf + (size_t)i * STAMP_WGS * 2;
 }
 
-enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_COUNT };
+enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_CHAIN, PC_COUNT };
 
 struct ProfScope {
     ymt3_ctx* c; hipStream_t s; bool on;
@@ -223,6 +227,7 @@ extern "C" void ymt3_destroy(ymt3_handle h) {
     }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->host_flag) (void)hipHostFree(h->host_flag);
+    if (h->chain_host_abort) (void)hipHostFree(h->chain_host_abort);
     if (h->host_rows) (void)hipHostFree(h->host_rows);
     for (int i = 0; i < 8; ++i) {
         if (h->chain_stream[i]) (void)hipStreamDestroy(h->chain_stream[i]);
@@ -335,6 +340,17 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->row_out, R * 8)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->ssq, (size_t)SSQ_TILES * R * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->opart, R * k.n_heads * d * 4)) return YMT3_ERR_HIP;
+    {   // the GEMM chain needs every workgroup of its grid resident at once: one 143 KB-LDS workgroup per CU, 256 CUs
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        if (prop.multiProcessorCount < 256 || init_chain_kernels()) c->gemm_chain = false;
+        if (c->gemm_chain) {
+            if (dev_alloc(c, (void**)&c->chain_sync, CHAIN_SYNC_WORDS * sizeof(unsigned))) return YMT3_ERR_HIP;
+            HIP_TRY(hipMemset(c->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->chain_host_abort), sizeof(unsigned), hipHostMallocDefault));
+            *c->chain_host_abort = 0u;
+        }
+    }
     if (k.dec_ffn == YMT3_FFN_MOE) {
         MoeArgs& m = c->moe;
         const size_t P = 2 * R;
@@ -361,6 +377,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     c->moe_fold_combine = !(mcl && mcl[0] == '1');
     const char* nfo = getenv("YMT3_NO_FOLD_O");          // A/B: keep the separate self-attention O-projection launch
     c->fold_o = !(nfo && nfo[0] == '1');
+    const char* ngc = getenv("YMT3_NO_GEMM_CHAIN");      // A/B: the skinny GEMMs between cross-attention and the next self-attention as four launches
+    c->gemm_chain = !(ngc && ngc[0] == '1');
     const char* nc = getenv("YMT3_CHAINS");
     if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
     const char* ct = getenv("YMT3_CHAIN_THREADS");
@@ -410,6 +428,9 @@ static int check_call(ymt3_handle h, int B) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");
     if (B < 0 || B > h->maxB) FAIL(YMT3_ERR_ARG, "B=%d outside [0, max_batch=%d]", B, h->maxB);
     HIP_TRY(hipSetDevice(h->device));
+    if (h->chain_host_abort && *static_cast<volatile unsigned*>(h->chain_host_abort))
+        FAIL(YMT3_ERR_HIP, "a decode GEMM-chain launch gave up waiting for one of its stages (> 50 ms; were all 256 CUs available to it?): the token ids "
+                           "of that call were overwritten with INT32_MIN and this handle refuses further work (YMT3_NO_GEMM_CHAIN=1 avoids the kernel)");
     return 0;
 }
 
@@ -612,6 +633,13 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     const bool fold_combine = k.dec_ffn == YMT3_FFN_MOE && h->moe_fold_combine && R < 512;
     float* hcur = h->h_dec;
     const float* pend = nullptr;
+    // GEMM chain (dec_chain.hip): after a layer's cross-attention, ONE launch does the cross O-projection, the FFN and the NEXT
+    // layer's QKV projection (or lm_head) -- decided per step shape, same bits as the four launches.  One chain per handle at a time
+    // (its arrival counters are per handle), so not with YMT3_CHAINS > 1 row ranges.
+    const bool chain = h->gemm_chain && h->chain_sync && h->fold_o && h->fuse_q && k.dec_ffn != YMT3_FFN_MOE && k.n_channels == 1 && H == 8 &&
+                       d == 512 && inner == 512 && k.d_ff == 2048 && R <= 64 && row0 == 0 && k.vocab % 32 == 0 && k.vocab / 32 >= 32 && k.vocab / 32 <= 64;
+    h->chain_used = chain;
+    bool qkv_done = false, lm_done = false;         // the previous layer's chain launch already did this layer's QKV / the lm_head
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const LayerW& W = LW[l];
         DecGemmArgs a{};
@@ -624,8 +652,11 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             a.h_out = hcur == h->h_dec ? h->h_dec2 : h->h_dec;
         }
         a.kcache = h->kcache + l * layer_cache; a.vcache = h->vcache + l * layer_cache;
-        a.stamp = next_stamp(h, PC_QKV, a.N / 16 * mtiles);
-        PLAUNCH(PC_QKV, launch_dec_gemm(DG_NORM_QKV_CACHE, a, s));
+        if (!qkv_done) {
+            a.stamp = next_stamp(h, PC_QKV, a.N / 16 * mtiles);
+            PLAUNCH(PC_QKV, launch_dec_gemm(DG_NORM_QKV_CACHE, a, s));
+        }
+        qkv_done = false;
         if (pend) { hcur = a.h_out; pend = nullptr; a.pend_y = nullptr; a.h_out = nullptr; }
         DecAttnArgs t{};
         t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
@@ -668,8 +699,27 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
         }
         if (!mc) {
+            if (chain) t.chain_sync = h->chain_sync;
             t.stamp = next_stamp(h, PC_CROSS_ATTN, R * H);
             PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));
+        }
+        if (chain) {
+            const bool last = l + 1 == k.n_dec_layers;
+            ChainArgs cg{};
+            cg.w0 = W.wo_c; cg.w1 = W.wi; cg.w2 = W.wo2; cg.w3 = last ? lm_head : LW[l + 1].wqkv;
+            cg.attn = h->dattn; cg.part = h->opart; cg.h = hcur; cg.ssq = h->ssq; cg.ssq_stride = h->maxR;
+            cg.gain1 = W.ln3;
+            if (last) GET(h, "dec.ln_f", 0u, const_cast<float**>(&cg.gain3), (size_t)d);
+            else cg.gain3 = LW[l + 1].ln1;
+            cg.dff = h->dff; cg.d_ff = k.d_ff;
+            cg.mode3 = last ? DG_NORM_LOGITS : DG_NORM_QKV_CACHE; cg.N3 = last ? k.vocab : 3 * inner;
+            cg.out_q = h->dq; cg.kcache = h->kcache + (size_t)(l + 1) * layer_cache; cg.vcache = h->vcache + (size_t)(l + 1) * layer_cache;
+            cg.logits = h->logits; cg.H = H; cg.L = L; cg.shared = shared; cg.row_pos = a.row_pos; cg.row0 = row0; cg.R = R; cg.eps = k.ln_eps;
+            cg.sync = h->chain_sync; cg.host_abort = h->chain_host_abort;
+            cg.stamp = next_stamp(h, PC_CHAIN, 256);
+            PLAUNCH(PC_CHAIN, launch_dec_chain(cg, s));
+            if (last) lm_done = true; else qkv_done = true;
+            continue;
         }
         a.a_bf16 = h->dattn; a.W = W.wo_c; a.N = d; a.K = inner;
         a.part = fold ? h->opart : nullptr;
@@ -699,8 +749,10 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     GET(h, "dec.ln_f", 0u, &f, (size_t)d);
     a.x_f32 = hcur; a.gain = f; a.W = lm_head; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
     a.pend_y = pend;                                 // the last layer's expert outputs, if their combine was folded away
-    a.stamp = next_stamp(h, PC_LM_HEAD, a.N / 16 * mtiles);
-    PLAUNCH(PC_LM_HEAD, launch_dec_gemm(DG_NORM_LOGITS, a, s));
+    if (!lm_done) {
+        a.stamp = next_stamp(h, PC_LM_HEAD, a.N / 16 * mtiles);
+        PLAUNCH(PC_LM_HEAD, launch_dec_gemm(DG_NORM_LOGITS, a, s));
+    }
     ArgmaxArgs g{};
     g.logits = h->logits; g.h = h->h_dec; g.shared = shared; g.finished = h->finished; g.ssq = h->ssq; g.ssq_stride = h->maxR; g.row0 = row0;
     g.R = R; g.V = k.vocab; g.d = d; g.n_channels = k.n_channels; g.eos_id = k.eos_id; g.pad_id = k.pad_id;
@@ -826,6 +878,8 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
             }
         }
     }
+    // a GEMM-chain launch that gave up on a stage (dec_chain.hip) must not leave plausible ids behind
+    if (h->chain_used) LAUNCH(launch_chain_poison(h->chain_sync, tokens, (long long)R * n_steps, s));
     HIP_TRY(hipGetLastError());
     return YMT3_OK;
 }
@@ -936,6 +990,8 @@ extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int
         }
         HIP_TRY(hipMemcpyAsync(h->host_rows, h->finished, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (h->chain_host_abort && *static_cast<volatile unsigned*>(h->chain_host_abort))
+            FAIL(YMT3_ERR_HIP, "a decode GEMM-chain launch gave up waiting for one of its stages; the ids of this call are invalid");
         free_slots.clear();
         for (int slot = 0; slot < slots; ++slot) {
             if (slot_seg[(size_t)slot] < 0) continue;
@@ -1025,7 +1081,9 @@ extern "C" int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* sta
     if (kernel < 0 || kernel >= h->stamp_n || capacity_wgs < h->stamp_grid[kernel]) FAIL(YMT3_ERR_ARG, "kernel=%d of %d, capacity %d", kernel, h->stamp_n, capacity_wgs);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(stamps, h->stamp_buf + (size_t)kernel * STAMP_WGS * 2, (size_t)h->stamp_grid[kernel] * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // the caller's capacity decides how much of the kernel's slot comes back (the GEMM chain keeps stage marks behind its [grid][2] stamps)
+    const size_t n_wgs = capacity_wgs < STAMP_WGS ? (size_t)capacity_wgs : (size_t)STAMP_WGS;
+    HIP_TRY(hipMemcpy(stamps, h->stamp_buf + (size_t)kernel * STAMP_WGS * 2, n_wgs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return YMT3_OK;
 }
 

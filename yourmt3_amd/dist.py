@@ -84,7 +84,12 @@ def init_distributed(n_gpus: int = 1) -> Tuple[int, int, int]:
         # YMT3_DIST_BACKEND=gloo lets several ranks rehearse on ONE GPU (RCCL refuses duplicate devices)
         backend = os.environ.get("YMT3_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            local_rank %= max(1, torch.cuda.device_count())
+            n_dev = max(1, torch.cuda.device_count())
+            if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > n_dev:
+                # several ranks rehearsing on one GPU: the decode GEMM chain (csrc/dec_chain.hip) needs every CU for ITS workgroups
+                # while it runs, and two of them from different processes can starve each other until both give up
+                os.environ.setdefault("YMT3_NO_GEMM_CHAIN", "1")
+            local_rank %= n_dev
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank)
