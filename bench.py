@@ -92,13 +92,16 @@ def pmc_file(name: str):
         return json.load(f)
 
 
-def pmc_traffic(cfg, B: int, L: int):
-    """HBM bytes per self-attention launch from the committed rocprofv3 PMC passes (profiles/, produced by
-    scripts/gpu_pmc.sh; FETCH_SIZE doubled per the gfx950 correction).  None if the profile does not match."""
-    d = pmc_file("r02_pmc_decode_attn.json") or pmc_file("r01_pmc_decode_attn.json")
-    if d is None or B != 64 or L != 1024 or cfg.n_channels != 1 or cfg.n_frames != 256:
+def pmc_traffic(cfg, B: int, L: int, paired: bool = False):
+    """HBM bytes per launch of the dominant attention kernel from the committed rocprofv3 PMC passes (profiles/, produced by
+    scripts/gpu_pmc.sh; FETCH_SIZE doubled per the gfx950 correction).  None if no profile matches the shape / kernel."""
+    if B != 64 or L != 1024 or cfg.n_channels != 1 or cfg.n_frames != 256:
         return None
-    return d["self_attn"]["hbm_bytes_per_launch"]
+    if paired:
+        d = pmc_file("r02_pmc_attn_pair.json")
+        return None if d is None else d["attn_pair"]["hbm_bytes_per_launch"]
+    d = pmc_file("r02_pmc_decode_attn.json") or pmc_file("r01_pmc_decode_attn.json")
+    return None if d is None else d["self_attn"]["hbm_bytes_per_launch"]
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -309,29 +312,37 @@ def roofline_block(model, cfg, audio, B, L, stride, sec_per_batch) -> dict:
     step_us = sum(us[k] * per_step[k] for k in kern)
 
     sa_bytes = sum(self_attn_bytes(cfg, rows, t) for t in sampled_t) / n_sampled
-    assert kern["self_attn"]["launches"] == n_sampled * cfg.n_dec_layers, (kern["self_attn"], n_sampled)
     ca_bytes = cross_attn_bytes(cfg, B)
     wb = decoder_weight_bytes(cfg)
+    # a layer's self- and cross-attention are one launch at this shape (dec_attn_pair_kernel): its bytes are both K/V streams
+    paired = "attn_pair" in kern
+    attn_name = "attn_pair" if paired else "self_attn"
+    attn_bytes = sa_bytes + ca_bytes if paired else sa_bytes
+    assert kern[attn_name]["launches"] == n_sampled * cfg.n_dec_layers, (kern[attn_name], n_sampled)
 
     def hbm(bytes_per_launch, name):
         gbs = bytes_per_launch / (us[name] * 1e-6) / 1e9
         return {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_us": us[name], "algorithmic_bytes_per_launch": bytes_per_launch,
                 "share_of_step": us[name] * per_step[name] / step_us}
 
-    sa = hbm(sa_bytes, "self_attn")
+    sa = hbm(attn_bytes, attn_name)
     shares = {k: us[k] * per_step[k] / step_us for k in kern}
     top = max(shares, key=shares.get)
+    kernel_label = {"self_attn": "dec_attn_kernel<true> (decoder self-attention over the KV cache)",
+                    "attn_pair": "dec_attn_pair_kernel (a decoder layer's self-attention over the KV cache + cross-attention over the encoder K/V, one launch)"}
     out["roofline"] = {
-        "kernel": "dec_attn_kernel<true> (decoder self-attention over the KV cache)" if top == "self_attn" else top,
+        "kernel": kernel_label.get(top, top),
         "bound": "hbm", "achieved": sa["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sa["frac"],
-        "traffic": pmc_traffic(cfg, B, L),
-        "avg_launch_us": sa["avg_launch_us"], "launches_timed": kern["self_attn"]["launches"], "event_pair_overhead_us": 1e3 * pair_ms,
+        "traffic": pmc_traffic(cfg, B, L, paired),
+        "avg_launch_us": sa["avg_launch_us"], "launches_timed": kern[attn_name]["launches"], "event_pair_overhead_us": 1e3 * pair_ms,
         "eager_step_us": 1e3 * step_true_ms, "share_of_step": sa["share_of_step"],
-        "algorithmic_bytes_per_launch": sa_bytes,
-        "note": "top kernel by aggregate share of the decode step; bytes = rows*heads*(t+1)*64*2B*2 (K and V) averaged over sampled positions "
-                "t = stride/2, 3*stride/2, ...; duration = HIP events around each sampled launch on the launch stream minus the per-bracket "
+        "algorithmic_bytes_per_launch": attn_bytes,
+        "note": "top kernel by aggregate share of the decode step; bytes = rows*heads*(t+1)*64*2B*2 (self K and V) averaged over sampled positions "
+                "t = stride/2, 3*stride/2, ... "
+                + ("+ segments*heads*frames*64*2B*2 (cross K and V); " if paired else "; ") +
+                "duration = HIP events around each sampled launch on the launch stream minus the per-bracket "
                 "overhead calibrated against un-bracketed steps; traffic = FETCH_SIZE*2 + WRITE_SIZE per launch from "
-                "profiles/r02_pmc_decode_attn.json (separate rocprofv3 --pmc passes)",
+                "the committed rocprofv3 --pmc passes under profiles/ (separate passes per counter)",
     }
     total_bytes = decode_bytes_per_batch(cfg, B, L)
     path_gbs = total_bytes / sec_per_batch / 1e9
@@ -348,6 +359,7 @@ def roofline_block(model, cfg, audio, B, L, stride, sec_per_batch) -> dict:
         n_chain = per_step["gemm_chain"]
         gemm_bytes += n_chain * (wb["cross_o_gemm"] + wb["ffn_wi_gemm"] + wb["ffn_wo_gemm"]) + (n_chain - 1) * wb["qkv_cache_gemm"] + wb["lm_head_gemm"]
     out["roofline_kernels"] = {
+        # (None when the cross-attention runs inside the attention-pair launch: the roofline entry above covers both streams)
         "cross_attn": hbm(ca_bytes + (wb["cross_q"] if "cross_q_gemm" not in kern else 0), "cross_attn") if "cross_attn" in kern else None,
         "dec_gemm_family": {"share_of_step": gemm_us / step_us, "launches_per_step": sum(per_step[k] for k in gemm_names),
                             "weight_bytes_per_step": gemm_bytes, "achieved": gemm_bytes / (gemm_us * 1e-6) / 1e9,

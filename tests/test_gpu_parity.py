@@ -650,10 +650,33 @@ def test_gemm_chain_is_bit_identical_to_the_four_launches(small, monkeypatch):
     old.close()
 
 
+def test_attention_pair_is_bit_identical_to_the_two_launches(monkeypatch):
+    """Round 2: a layer's self-attention (with its folded O-projection) and fused cross-attention run as ONE launch; the row's eight
+    heads hand their partials over through a per-row arrival counter and agent-scope stores / loads.  Logits and ids must not move
+    by one bit against YMT3_NO_ATTN_PAIR=1, at ragged and full row counts, short and long positions, lock-step and slot mode."""
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=160)
+    monkeypatch.setenv("YMT3_NO_ATTN_PAIR", "1")
+    old = _model(cfg, max_batch=64)
+    monkeypatch.delenv("YMT3_NO_ATTN_PAIR")
+    new = _model(cfg, max_batch=64)
+    for B, n in ((1, 160), (5, 160), (37, 40), (64, 150)):
+        a = O.synthetic_audio(B, cfg, seed=50 + B).cuda()
+        e = new.encode(new.logmel(a))
+        t_new, l_new = new.decode(e, n, return_logits=True)
+        t_old, l_old = old.decode(e, n, return_logits=True)
+        assert torch.equal(t_new, t_old) and torch.equal(l_new, l_old), (B, n)
+        assert int(t_new.min()) >= 0
+    a = O.synthetic_audio(11, cfg, seed=78).cuda()
+    assert torch.equal(new.inference_stream(a, slots=6, interval=4, max_token_length=48), old.inference_stream(a, slots=6, interval=4, max_token_length=48))
+    new.close()
+    old.close()
+
+
 def test_profile_hooks(small):
     e = small.encode(small.logmel(O.synthetic_audio(2, SMALL).cuda()))
     prof = small.profile_decode(e, 32, stride=8)
-    assert prof["self_attn"]["launches"] == 4 * SMALL.n_dec_layers and prof["self_attn"]["ms_total"] > 0
+    # a layer's self- and cross-attention are one launch (dec_attn_pair_kernel)
+    assert prof["attn_pair"]["launches"] == 4 * SMALL.n_dec_layers and prof["attn_pair"]["ms_total"] > 0 and prof["self_attn"]["launches"] == 0
     # the last layer's GEMM-chain launch ends with lm_head (dec_chain.hip): one chain launch per layer, no lm_head launch of its own
     assert prof["gemm_chain"]["launches"] == 4 * SMALL.n_dec_layers and prof["lm_head_gemm"]["launches"] == 0
     assert prof["qkv_cache_gemm"]["launches"] == 4 and prof["ffn_wi_gemm"]["launches"] == 0
@@ -697,8 +720,8 @@ def test_step_stamps_hook(small, monkeypatch):
     plain = small.inference(a.cuda(), max_token_length=8)
     assert torch.equal(m.inference(a.cuda(), max_token_length=8), plain)       # stamping changes no result
     rows = m.step_stamps()
-    assert len(rows) == 1 + 3 * 6 + 1 and rows[0][0] == "qkv_cache_gemm" and rows[-1][0] == "argmax_embed"  # 20 launches per step
-    assert [r[0] for r in rows[:5]] == ["qkv_cache_gemm", "self_attn", "cross_attn", "gemm_chain", "self_attn"]
+    assert len(rows) == 1 + 2 * 6 + 1 and rows[0][0] == "qkv_cache_gemm" and rows[-1][0] == "argmax_embed"  # 14 launches per step
+    assert [r[0] for r in rows[:4]] == ["qkv_cache_gemm", "attn_pair", "gemm_chain", "attn_pair"]
     prev_exit = 0.0
     for name, grid, in0, in1, out0, out1 in rows:
         assert grid > 0 and in0 <= in1 and in0 <= out0 <= out1, (name, in0, in1, out0, out1)

@@ -43,6 +43,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define YMT3_STAMP_PHASE 0           // 1 / 2: timing-only builds that move dec_gemm_kernel's entry stamp to a later phase (tools, not product)
 #endif
 #define STAMP_IN(a) do { if ((a).stamp && threadIdx.x == 0) (a).stamp[2 * blockIdx.x] = wall_clock64(); } while (0)
+// attention pair only: stage marks behind the [grid][2] stamps of the kernel's slot (1024 words for its 512 workgroups), 8 per workgroup
+#define PAIR_MARK(a, k, v) do { if ((a).stamp && threadIdx.x == 0) (a).stamp[1024 + 8 * blockIdx.x + (k)] = (v); } while (0)
 #define STAMP_OUT(a) do { if ((a).stamp && (threadIdx.x & 63) == 0) atomicMax((a).stamp + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64()); } while (0)
 
 // ------------------------------------------------------------------------------------------------
@@ -511,14 +513,53 @@ __device__ __forceinline__ float sum8(float v) {
 // before the K/V stream (L2 hits, no registers) and sit in LDS until the tail.  FUSEQ cross-attention: the residual row is
 // h + (p0 + ... + p7), summed in wave order as DG_RESID's reduction does, and sum(x^2) is rebuilt with DG_RESID's tree
 // (pairs, then the 16-column tiles) followed by the 32-tile wave sum the ssq consumers use: one launch less per layer, same bits.
-template <bool SELF, bool FUSEQ, int NW, bool OP = false>
-__global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __restrict__ pK, const bf16_t* __restrict__ pV, const bf16_t* __restrict__ pQ,
-                                                              const float* __restrict__ pF, const void* __restrict__ p4, const void* __restrict__ p5,
-                                                              unsigned geom0, unsigned geom1, DecAttnArgs a) {   // 4 waves / SIMD -> <= 128 VGPRs
+// PAIR (dec_attn_pair_kernel below: a layer's self- and cross-attention as one launch): 1 = the self-attention half -- its
+// O-projection partials leave at agent scope, the caller signals the row; 2 = the cross-attention half -- it requests everything that
+// does not depend on the self-attention (its head's wq, the residual row, its K/V block), THEN waits for the row's eight heads and
+// reads their partials at agent scope.
+struct PairSync {
+    unsigned* rows;             // [R][2] lines of CHAIN_LINE words: arrivals, departures (the eighth to leave zeroes both)
+    unsigned* abort_word;       // the handle's sticky abort word (shared with the GEMM chain)
+    unsigned* host_abort;
+};
+__device__ __forceinline__ void pair_wait(const PairSync& ps, int r) {
+    if (threadIdx.x == 0) {
+        unsigned* arr = ps.rows + (size_t)(2 * r) * CHAIN_LINE;
+        unsigned* dep = arr + CHAIN_LINE;
+        unsigned long long t0 = 0;
+        unsigned polls = 0;
+        bool ok = true;
+        while (__hip_atomic_load(arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u) {
+            if ((++polls & 63u) == 0u) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (__hip_atomic_load(ps.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > 5000000ull) {      // 50 ms
+                    __hip_atomic_store(ps.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ps.host_abort) __hip_atomic_store(ps.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        // the last of the row's eight heads to get here leaves both counters at zero for the next launch
+        if (ok && __hip_atomic_fetch_add(dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7u) {
+            __hip_atomic_store(arr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dep, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+}
+
+template <bool SELF, bool FUSEQ, int NW, bool OP, int PAIR>
+__device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const bf16_t* __restrict__ pV, const bf16_t* __restrict__ pQ,
+                                          const float* __restrict__ pF, const void* __restrict__ p4, const void* __restrict__ p5,
+                                          unsigned geom0, unsigned geom1, const DecAttnArgs& a, const PairSync& ps) {
     // Leading scalar arguments (14 dwords; kernarg preload, see dec_gemm_kernel) -- everything the first loads' addresses depend
     // on: K / V slab bases, pQ = q (wq when FUSEQ), pF = the position-bias table (SELF) or the residual stream (FUSEQ),
     // p4 / p5 = loop state and per-row positions (SELF) or norm gain and sum(h^2) partials / O-projection partials (FUSEQ),
     // geom0 = row0 | rows_per_kv << 16 | H << 24, geom1 = slab_keys | n_keys_const << 20.
+    unsigned long long t_entry = 0;
+    if constexpr (PAIR == 1) t_entry = wall_clock64();          // measurement: stored with the entry stamp, behind the first loads
     const int row0 = geom0 & 0xffff, rows_per_kv = (geom0 >> 16) & 0xff, H = geom0 >> 24;
     const int slab_keys = geom1 & 0xfffff, n_keys_const = geom1 >> 20;
     const DecodeShared* pShared = static_cast<const DecodeShared*>(p4);
@@ -544,7 +585,10 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __re
     const float* bias = SELF ? pF + (size_t)h * slab_keys : nullptr;      // the bias table's row pitch is the cache length (launcher checks)
     if constexpr (OP && SELF) {
         // this wave's 64 rows of wo (output columns 64w..64w+63), the head's 64 k each: 8 DMAs of 8 rows x 128 B.  LDS slot
-        // (row, pos) holds source chunk pos ^ (row & 7): the swizzle sits on the source address, the DMA writes linearly
+        // (row, pos) holds source chunk pos ^ (row & 7): the swizzle sits on the source address, the DMA writes linearly.
+        // (Requested at entry although hipcc's vmcnt(0) for q, in front of the key loop, then also waits for them: requested when the
+        // stream has been consumed instead, they land under the merge and lengthen the tail by more than the head gains --
+        // 259.5 against 253.9 ms per batch, profiles/r02_attn_pair_marks.txt.)
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wo_lds + (unsigned)wave * 8192u;
         const bf16_t* src = a.wo + ((size_t)(wave * 64 + (lane >> 3)) * H + h) * DKV + ((lane & 7) ^ (lane >> 3)) * 8;
 #pragma unroll
@@ -564,8 +608,10 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __re
         x_v = pF[(size_t)r * 512 + tid];
         g_v = pGain[tid];
         if constexpr (OP) {
+            if constexpr (PAIR != 2) {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) pv[w] = pPart[((size_t)r * H + w) * 512 + tid];
+                for (int w = 0; w < 8; ++w) pv[w] = pPart[((size_t)r * H + w) * 512 + tid];
+            }
         } else {
             if (tid < SSQ_TILES) ss = pPart[(size_t)tid * a.ssq_stride + r];
         }
@@ -576,7 +622,8 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __re
     float m = -1.0e30f, l = 0.f, acc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.f;
-    STAMP_IN(a);                               // (reads a.stamp from the kernarg segment: behind the first loads, not in front of them)
+    if constexpr (PAIR != 2) STAMP_IN(a);      // (reads a.stamp from the kernarg segment: behind the first loads, not in front of them)
+    if constexpr (PAIR == 1) PAIR_MARK(a, 0, t_entry);
 
     // The self-attention cache (up to 805 MB) is read exactly once per step: non-temporal loads keep it
     // from evicting the weights (42 MB) and the cross-attention K/V (201 MB at 64 segments), both
@@ -666,7 +713,28 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __re
         // every wave's projection operands are requested before ANY wave's K/V: the CU returns vector-memory data in request
         // order, so weight lines (L2 hits) queued behind another wave's K/V lines (HBM) reached the projection only after
         // most of the stream had arrived, and the projection ran exposed at the end (+2.7 us, profiles/r01_step_stamps.txt)
-        __builtin_amdgcn_s_barrier();
+        if constexpr (PAIR == 2) {
+            // The projection's own operands are in flight (10 loads per lane: 8 wq, x, gain).  The self-attention half's partial
+            // stores are OLDER than these and vector-memory operations retire in issue order, so a wait that leaves 10 outstanding
+            // has seen them acknowledged: signal the row, wait for its eight heads, read their partials at agent scope.  The K/V
+            // block is requested AFTER this.  Requested before the hand-off, a poll (and the partials) came back behind it, in issue
+            // order, i.e. only once the whole block had arrived (254.5 ms per batch against 253.9); requested by the self-attention half
+            // as soon as its own stream was consumed, it slowed the other workgroups' self-attention streams by more than it gained
+            // (263 ms; profiles/r02_attn_pair_marks.txt).  (The pair kernel keeps hipcc from moving memory operations across the
+            // boundary between the halves.)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(ps.rows + (size_t)(2 * r) * CHAIN_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PAIR_MARK(a, 3, wall_clock64());     // row signalled
+            pair_wait(ps, r);
+            PAIR_MARK(a, 4, wall_clock64());     // the row's eight heads have arrived
+#pragma unroll
+            for (int w = 0; w < 8; ++w) pv[w] = __hip_atomic_load(pPart + ((size_t)r * H + w) * 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            __builtin_amdgcn_s_barrier();
+        }
     }
     if constexpr (FUSEQ) {
         // first (for T <= 256: only) K/V block goes in flight now; its math waits for the projection below.  STRAIGHT-LINE
@@ -732,6 +800,8 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __re
             compute_block(fku, fvu, fok, fbv, std::false_type{});
         }
     }
+    if constexpr (PAIR == 1) PAIR_MARK(a, 1, wall_clock64());     // self-attention stream consumed
+    if constexpr (PAIR == 2) PAIR_MARK(a, 5, wall_clock64());     // cross-attention block consumed
     // merge the 8 key groups of the wave (lanes with equal `sub`)
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) {
@@ -785,14 +855,45 @@ __global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __re
         }
         if (li == 0) {
             float* dst = a.opart + ((size_t)r * H + h) * 512 + wave * 64 + g * 4;
+            if constexpr (PAIR == 1) {           // read by the row's other heads, on other XCDs, later in this launch: agent scope (aux 16 = sc1)
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.opart, 0, 0x7fffffff, 0x00020000);
+                const int off = (((r * H + h) * 512) + wave * 64 + g * 4) * 4;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(dst + c * 16) = make_float4(pa[c][0], pa[c][1], pa[c][2], pa[c][3]);
+                for (int c = 0; c < 4; ++c) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pa[c]), ro, off + c * 64, 0, 16);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(dst + c * 16) = make_float4(pa[c][0], pa[c][1], pa[c][2], pa[c][3]);
+            }
         }
     }
     if constexpr (FUSEQ) {
         if (a.chain_sync && blockIdx.x == 0 && tid < CHAIN_COUNTERS) a.chain_sync[tid * CHAIN_LINE] = 0u;      // the next launch's arrival counters (dec_chain.hip)
     }
-    STAMP_OUT(a);
+    if constexpr (PAIR == 1) PAIR_MARK(a, 2, wall_clock64());     // O-projection partial stored
+    if constexpr (PAIR != 1) STAMP_OUT(a);
+}
+
+template <bool SELF, bool FUSEQ, int NW, bool OP = false>
+__global__ __launch_bounds__(64 * NW, 4) void dec_attn_kernel(const bf16_t* __restrict__ pK, const bf16_t* __restrict__ pV, const bf16_t* __restrict__ pQ,
+                                                              const float* __restrict__ pF, const void* __restrict__ p4, const void* __restrict__ p5,
+                                                              unsigned geom0, unsigned geom1, DecAttnArgs a) {   // 4 waves / SIMD -> <= 128 VGPRs
+    attn_body<SELF, FUSEQ, NW, OP, 0>(pK, pV, pQ, pF, p4, p5, geom0, geom1, a, PairSync{});
+}
+
+// A layer's self-attention and cross-attention as ONE launch (up to 64 rows: 512 workgroups, two per CU, all resident).  Workgroup
+// (row, head) streams its self-attention slab and leaves its O-projection partial (the folded form above), signals the row, requests
+// its cross-attention operands, waits for the row's eight heads and goes on as the fused cross-attention.  What that saves is the
+// launch gap and the cross-attention's start-up: its K/V stream is requested ~1 us after the self-attention's last bytes instead of
+// after a kernel boundary and a dispatch ramp.  Same arithmetic as the two launches, bit for bit.
+__global__ __launch_bounds__(512, 4) void dec_attn_pair_kernel(const bf16_t* __restrict__ pK, const bf16_t* __restrict__ pV, const bf16_t* __restrict__ pQ,
+                                                               const float* __restrict__ pF, const void* __restrict__ p4, const void* __restrict__ p5,
+                                                               unsigned geom0, unsigned geom1, DecAttnArgs a, DecAttnArgs b, unsigned gb0, unsigned gb1,
+                                                               PairSync ps) {
+    attn_body<true, false, 8, true, 1>(pK, pV, pQ, pF, p4, p5, geom0, geom1, a, ps);
+    // the second half counts its loads against the first half's stores (see PAIR == 2): nothing may cross this line
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    attn_body<false, true, 8, true, 2>(b.k, b.v, b.wq, b.x_f32, b.gain, b.ipart, gb0, gb1, b, ps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -996,6 +1097,7 @@ int init_decode_kernels() {
     rc |= launch_dg<DG_NORM_QKV_CACHE, 512, 2, true>(z, nullptr);
     rc |= launch_dg<DG_NORM_LOGITS, 512, 1, true>(z, nullptr);
     rc |= launch_dg<DG_NORM_LOGITS, 512, 2, true>(z, nullptr);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WO_LDS_BYTES) != hipSuccess) rc |= -2;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             WO_LDS_BYTES) != hipSuccess) rc |= -2;
     return rc;
@@ -1079,6 +1181,21 @@ int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t strea
         else ATTN(false, false, 8, false, 512, 0, a.q, nullptr, nullptr, nullptr);
     }
 #undef ATTN
+    return 0;
+}
+
+// self-attention (folded O-projection) + fused cross-attention of one layer as one launch; < 0: not this kernel's shape
+int launch_dec_attention_pair(const DecAttnArgs& a, const DecAttnArgs& b, unsigned* pair_rows, unsigned* abort_word, unsigned* host_abort,
+                              hipStream_t stream) {
+    if (a.R <= 0) return 0;
+    if (a.R > 64 || a.R != b.R || a.row0 != b.row0 || a.H != 8 || b.H != 8 || !a.wo || !a.opart || !b.wq || b.ipart != a.opart || !pair_rows || !abort_word ||
+        a.rows_per_kv != 1 || b.rows_per_kv < 1 || b.rows_per_kv > 0xff || a.row0 < 0 || a.row0 > 0xffff || a.slab_keys < 1 || a.slab_keys > 0xfffff ||
+        b.slab_keys < 1 || b.slab_keys > 0xfffff || b.n_keys_const < 1 || b.n_keys_const > 0xfff || a.bias_stride != a.slab_keys)
+        return -1;
+    const unsigned g0 = (unsigned)a.row0 | 1u << 16 | 8u << 24, g1 = (unsigned)a.slab_keys;
+    const unsigned h0 = (unsigned)b.row0 | (unsigned)b.rows_per_kv << 16 | 8u << 24, h1 = (unsigned)b.slab_keys | (unsigned)b.n_keys_const << 20;
+    dec_attn_pair_kernel<<<a.R * 8, 512, WO_LDS_BYTES, stream>>>(a.k, a.v, a.q, a.bias, a.shared, a.row_pos, g0, g1, a, b, h0, h1,
+                                                                 PairSync{pair_rows, abort_word, host_abort});
     return 0;
 }
 

@@ -181,6 +181,10 @@ struct DecAttnArgs {
     unsigned* chain_sync;       // fused cross-attention, or null: the arrival counters of the GEMM chain launched next (dec_chain.hip), zeroed here
 };
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream);
+// one layer's self-attention (folded O-projection) and fused cross-attention as one launch (decode.hip: dec_attn_pair_kernel);
+// pair_rows = [R][2] zeroed 128-byte counter lines the kernel leaves zeroed; 0 launched, < 0 not this kernel's shape
+int launch_dec_attention_pair(const DecAttnArgs& self_args, const DecAttnArgs& cross_args, unsigned* pair_rows, unsigned* abort_word,
+                              unsigned* host_abort, hipStream_t stream);
 
 // multi-channel cross-attention with the query projection fused, one workgroup per (segment, head) (mc_cross_attn.hip)
 struct McCrossArgs {

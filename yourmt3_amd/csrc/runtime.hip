@@ -107,6 +107,8 @@ struct ymt3_ctx {
     unsigned* chain_sync = nullptr;         // [CHAIN_SYNC_WORDS] device: the chain kernel's arrival counters + sticky abort word
     unsigned* chain_host_abort = nullptr;   // pinned: set by the chain kernel together with the abort word; checked at every call
     bool chain_used = false;                // the last captured / launched step contains chain launches
+    bool attn_pair = true;                  // a layer's self- and cross-attention as one launch (decode.hip: dec_attn_pair_kernel; YMT3_NO_ATTN_PAIR=1: two)
+    unsigned* pair_rows = nullptr;          // [maxR <= 64][2] counter lines of that kernel (zero between launches)
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
     size_t prof_span_idx = 0;
@@ -135,7 +137,7 @@ static unsigned long long* next_stamp(ymt3_ctx* c, int cls, int grid) {
     return c->stamp_buf + (size_t)i * STAMP_WGS * 2;
 }
 
-enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_CHAIN, PC_COUNT };
+enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_CHAIN, PC_ATTN_PAIR, PC_COUNT };
 
 struct ProfScope {
     ymt3_ctx* c; hipStream_t s; bool on;
@@ -349,6 +351,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
             HIP_TRY(hipMemset(c->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->chain_host_abort), sizeof(unsigned), hipHostMallocDefault));
             *c->chain_host_abort = 0u;
+            if (dev_alloc(c, (void**)&c->pair_rows, (size_t)64 * 2 * CHAIN_LINE * sizeof(unsigned))) return YMT3_ERR_HIP;
+            HIP_TRY(hipMemset(c->pair_rows, 0, (size_t)64 * 2 * CHAIN_LINE * sizeof(unsigned)));
         }
     }
     if (k.dec_ffn == YMT3_FFN_MOE) {
@@ -379,6 +383,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     c->fold_o = !(nfo && nfo[0] == '1');
     const char* ngc = getenv("YMT3_NO_GEMM_CHAIN");      // A/B: the skinny GEMMs between cross-attention and the next self-attention as four launches
     c->gemm_chain = !(ngc && ngc[0] == '1');
+    const char* nap = getenv("YMT3_NO_ATTN_PAIR");       // A/B: self-attention and cross-attention as two launches
+    c->attn_pair = !(nap && nap[0] == '1');
     const char* nc = getenv("YMT3_CHAINS");
     if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
     const char* ct = getenv("YMT3_CHAIN_THREADS");
@@ -671,8 +677,14 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         // -1.4 % at 128, -3.5 % at 256 (profiles/r02_b256_fold_fuseq_variants.txt); same bits either way
         const bool fold = h->fold_o && h->fuse_q && !mc && H == 8 && d == 512 && R <= 96;
         if (fold) { t.wo = W.wo; t.opart = h->opart; }
-        t.stamp = next_stamp(h, PC_SELF_ATTN, R * H);
-        PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
+        // attention pair (decode.hip: dec_attn_pair_kernel): with the GEMM chain's shape (dense FFN, one channel, up to 64 rows, folded
+        // O-projection, fused query projection) the layer's two attention kernels run as one launch
+        const bool pair = chain && h->attn_pair && h->pair_rows;
+        DecAttnArgs ts = t;                          // the self-attention half
+        if (!pair) {
+            t.stamp = next_stamp(h, PC_SELF_ATTN, R * H);
+            PLAUNCH(PC_SELF_ATTN, launch_dec_attention(true, t, s));
+        }
         t.wo = nullptr; t.opart = nullptr;
         a.a_bf16 = h->dattn; a.W = W.wo; a.N = d; a.K = inner; a.out_f32 = hcur;
         if (!fold) {
@@ -698,7 +710,11 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             a.stamp = next_stamp(h, PC_CROSS_Q, a.N / 16 * mtiles);
             PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
         }
-        if (!mc) {
+        if (pair) {
+            t.chain_sync = h->chain_sync;
+            ts.stamp = t.stamp = next_stamp(h, PC_ATTN_PAIR, R * H);
+            PLAUNCH(PC_ATTN_PAIR, launch_dec_attention_pair(ts, t, h->pair_rows, h->chain_sync + CHAIN_ABORT_WORD, h->chain_host_abort, s));
+        } else if (!mc) {
             if (chain) t.chain_sync = h->chain_sync;
             t.stamp = next_stamp(h, PC_CROSS_ATTN, R * H);
             PLAUNCH(PC_CROSS_ATTN, launch_dec_attention(false, t, s));

@@ -163,7 +163,7 @@ class YourMT3:
         return out
 
     PROFILE_CLASSES = ["qkv_cache_gemm", "self_attn", "self_o_gemm", "cross_q_gemm", "cross_attn", "cross_o_gemm",
-                       "ffn_wi_gemm", "ffn_wo_gemm", "lm_head_gemm", "argmax_embed", "unsampled_span", "gemm_chain"]
+                       "ffn_wi_gemm", "ffn_wo_gemm", "lm_head_gemm", "argmax_embed", "unsampled_span", "gemm_chain", "attn_pair"]
 
     def profile_decode(self, enc: torch.Tensor, n_steps: int, stride: int = 16) -> Dict[str, dict]:
         """Eager decode with HIP events around each kernel of every `stride`-th step (include/ymt3.h)."""
