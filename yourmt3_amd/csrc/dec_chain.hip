@@ -145,9 +145,26 @@ __device__ __forceinline__ float2 resid_out(float2 hold, float2 s, float* pH, fl
 }
 
 // a NORM-mode tile (K = 512, 32 columns): x rows and sum(h^2) partials in at agent scope, weights already in registers
+// What a NORM-mode tile can do BEFORE the stage in front of it has finished: park its weight slices in the LDS strips (the caller has
+// just passed a workgroup barrier: nobody reads the previous stage's LDS any more).  Its slice of the norm gain is fetched at kernel
+// entry with the weights: a load issued here would sit in front of the poll loop's loads, which return in issue order.
+__device__ __forceinline__ f32x4 norm_gain(const float* gain) {
+    using G = Geo<512, 2>;
+    return *reinterpret_cast<const f32x4*>(gain + (threadIdx.x >> 6) * G::KW + ((threadIdx.x & 63) % G::LPRX) * 4);
+}
+template <int NT>
+__device__ __forceinline__ void norm_park(char* smem, u32x4 (&wv)[Geo<512, NT>::NIW]) {   // (hipcc mis-parses the array reference as a first parameter)
+    using G = Geo<512, NT>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* sW = smem + (8 * 16 * G::COLS + 16) * 4 + wave * (1 + NT) * G::STRIP + G::STRIP;
+#pragma unroll
+    for (int i = 0; i < G::NIW; ++i)
+        *reinterpret_cast<u32x4*>(sW + (i * G::RPIW + lane / G::LPRW) * G::PITCH + (lane % G::LPRW) * 16) = wv[i];
+}
+
 template <int MODE>
-__device__ __forceinline__ void norm_tile(const ChainArgs& c, const float* pH, int row0, int R, const float* gain, int N, int nt_idx, int mt_idx,
-                                          u32x4 (&wv)[Geo<512, 2>::NIW], int step, char* smem) {
+__device__ __forceinline__ void norm_tile(const ChainArgs& c, const float* pH, int row0, int R, const f32x4 gv, int N, int nt_idx, int mt_idx,
+                                          int step, char* smem) {
     using G = Geo<512, 2>;
     constexpr int NT = 2;
     float* red = reinterpret_cast<float*>(smem);
@@ -165,7 +182,6 @@ __device__ __forceinline__ void norm_tile(const ChainArgs& c, const float* pH, i
         mm = mm < m_end ? mm : m_end - 1;
         xv[i] = __builtin_bit_cast(f32x4, ld16_agent(rx, (mm * 512 + wave * G::KW + (lane % G::LPRX) * 4) * 4));
     }
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(gain + wave * G::KW + (lane % G::LPRX) * 4);
     float ss = 0.f;
     if (tid < 16 * 8) {
         const int mm = m0 + (tid >> 3) < m_end ? m0 + (tid >> 3) : m_end - 1;
@@ -176,9 +192,6 @@ __device__ __forceinline__ void norm_tile(const ChainArgs& c, const float* pH, i
     ss += __shfl_xor(ss, 2, 64);
     ss += __shfl_xor(ss, 4, 64);
     if (tid < 16 * 8 && (tid & 7) == 0) sscale[tid >> 3] = rsqrtf(ss / 512.f + c.eps);
-#pragma unroll
-    for (int i = 0; i < G::NIW; ++i)
-        *reinterpret_cast<u32x4*>(sW + (i * G::RPIW + lane / G::LPRW) * G::PITCH + (lane % G::LPRW) * 16) = wv[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < G::NIX; ++i) {
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(512) void dec_chain_kernel(const bf16_t* __restrict
     load_w<512, 2>(pW1, nt1 * 32, w1);
     load_w<2048, 1>(pW2, nt0 * 16, w2);
     load_w<512, 2>(pW3, nt3 * 32, w3);
+    const f32x4 g1 = norm_gain(c.gain1), g3 = norm_gain(c.gain3);
     __builtin_amdgcn_sched_barrier(0);
     CH_STAMP_IN(c);
 
@@ -292,21 +306,25 @@ __global__ __launch_bounds__(512) void dec_chain_kernel(const bf16_t* __restrict
     }
     // ---- stage 1: FFN-in
     if (has1) {
+        norm_park<2>(smem, w1);
         chain_wait(c.sync, 0, mt1, 32u, c.host_abort);
         CH_MARK(c, 2);
-        norm_tile<DG_NORM_BF16_RELU>(c, pH, row0, R, c.gain1, c.d_ff, nt1, mt1, w1, 0, smem);
+        norm_tile<DG_NORM_BF16_RELU>(c, pH, row0, R, g1, c.d_ff, nt1, mt1, 0, smem);
         CH_MARK(c, 3);
         chain_signal(c.sync, 1, mt1);
         CH_MARK(c, 4);
     }
     // ---- stage 2: FFN-out (the tile of stage 0 again: its h values are still in registers)
     if (has0) {
-        chain_wait(c.sync, 1, mt0, (unsigned)(c.d_ff / 32), c.host_abort);
-        CH_MARK(c, 5);
         float* red = reinterpret_cast<float*>(smem);
         char* strips = smem + (8 * 16 * 16 + 16) * 4;
         char* sA = strips + wave * 2 * G2::STRIP;
         char* sW = sA + G2::STRIP;
+#pragma unroll
+        for (int i = 0; i < G2::NIW; ++i)          // the weight slices are parked while the FFN-in stage is still running
+            *reinterpret_cast<u32x4*>(sW + (i * G2::RPIW + lane / G2::LPRW) * G2::PITCH + (lane % G2::LPRW) * 16) = w2[i];
+        chain_wait(c.sync, 1, mt0, (unsigned)(c.d_ff / 32), c.host_abort);
+        CH_MARK(c, 5);
         const __amdgpu_buffer_rsrc_t ra = raw_rsrc(c.dff);
         u32x4 dv[G2::NIA];
 #pragma unroll
@@ -316,11 +334,8 @@ __global__ __launch_bounds__(512) void dec_chain_kernel(const bf16_t* __restrict
             dv[i] = ld16_agent(ra, (mm * 2048 + wave * G2::KW + (lane % G2::LPRW) * 8) * 2);
         }
 #pragma unroll
-        for (int i = 0; i < G2::NIW; ++i) {
-            const int off = (i * G2::RPIW + lane / G2::LPRW) * G2::PITCH + (lane % G2::LPRW) * 16;
-            *reinterpret_cast<u32x4*>(sW + off) = w2[i];
-            *reinterpret_cast<u32x4*>(sA + off) = dv[i];
-        }
+        for (int i = 0; i < G2::NIA; ++i)
+            *reinterpret_cast<u32x4*>(sA + (i * G2::RPIW + lane / G2::LPRW) * G2::PITCH + (lane % G2::LPRW) * 16) = dv[i];
         const float2 s = mfma_reduce<2048, 1>(sA, sW, red);
         resid_out(o0, s, pH, c.ssq, c.ssq_stride, mE, nE, nt0, live0);
         CH_MARK(c, 6);
@@ -328,9 +343,10 @@ __global__ __launch_bounds__(512) void dec_chain_kernel(const bf16_t* __restrict
     }
     // ---- stage 3: the next layer's QKV projection, or lm_head
     if (has3) {
+        norm_park<2>(smem, w3);
         chain_wait(c.sync, 2, mt3, 32u, c.host_abort);
         CH_MARK(c, 7);
-        norm_tile<MODE3>(c, pH, row0, R, c.gain3, c.N3, nt3, mt3, w3, step, smem);
+        norm_tile<MODE3>(c, pH, row0, R, g3, c.N3, nt3, mt3, step, smem);
     }
     CH_STAMP_OUT(c);
 }

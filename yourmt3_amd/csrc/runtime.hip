@@ -345,8 +345,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     {   // the GEMM chain needs every workgroup of its grid resident at once: one 143 KB-LDS workgroup per CU, 256 CUs
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-        if (prop.multiProcessorCount < 256 || init_chain_kernels()) c->gemm_chain = false;
-        if (c->gemm_chain) {
+        if (prop.multiProcessorCount < 256 || init_chain_kernels()) c->gemm_chain = c->attn_pair = false;
+        if (c->gemm_chain || c->attn_pair) {
             if (dev_alloc(c, (void**)&c->chain_sync, CHAIN_SYNC_WORDS * sizeof(unsigned))) return YMT3_ERR_HIP;
             HIP_TRY(hipMemset(c->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->chain_host_abort), sizeof(unsigned), hipHostMallocDefault));
@@ -644,7 +644,10 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     // (its arrival counters are per handle), so not with YMT3_CHAINS > 1 row ranges.
     const bool chain = h->gemm_chain && h->chain_sync && h->fold_o && h->fuse_q && k.dec_ffn != YMT3_FFN_MOE && k.n_channels == 1 && H == 8 &&
                        d == 512 && inner == 512 && k.d_ff == 2048 && R <= 64 && row0 == 0 && k.vocab % 32 == 0 && k.vocab / 32 >= 32 && k.vocab / 32 <= 64;
-    h->chain_used = chain;
+    // attention pair (decode.hip: dec_attn_pair_kernel): a layer's two attention kernels as one launch wherever the folded
+    // O-projection and the fused query projection apply to one channel of up to 64 rows (dense or MoE FFN alike)
+    const bool pair_ok = h->attn_pair && h->pair_rows && h->fold_o && h->fuse_q && k.n_channels == 1 && H == 8 && d == 512 && R <= 64 && row0 == 0;
+    h->chain_used = chain || pair_ok;
     bool qkv_done = false, lm_done = false;         // the previous layer's chain launch already did this layer's QKV / the lm_head
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const LayerW& W = LW[l];
@@ -677,9 +680,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         // -1.4 % at 128, -3.5 % at 256 (profiles/r02_b256_fold_fuseq_variants.txt); same bits either way
         const bool fold = h->fold_o && h->fuse_q && !mc && H == 8 && d == 512 && R <= 96;
         if (fold) { t.wo = W.wo; t.opart = h->opart; }
-        // attention pair (decode.hip: dec_attn_pair_kernel): with the GEMM chain's shape (dense FFN, one channel, up to 64 rows, folded
-        // O-projection, fused query projection) the layer's two attention kernels run as one launch
-        const bool pair = chain && h->attn_pair && h->pair_rows;
+        const bool pair = pair_ok && fold;
         DecAttnArgs ts = t;                          // the self-attention half
         if (!pair) {
             t.stamp = next_stamp(h, PC_SELF_ATTN, R * H);
@@ -711,7 +712,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
         }
         if (pair) {
-            t.chain_sync = h->chain_sync;
+            if (chain) t.chain_sync = h->chain_sync;
             ts.stamp = t.stamp = next_stamp(h, PC_ATTN_PAIR, R * H);
             PLAUNCH(PC_ATTN_PAIR, launch_dec_attention_pair(ts, t, h->pair_rows, h->chain_sync + CHAIN_ABORT_WORD, h->chain_host_abort, s));
         } else if (!mc) {

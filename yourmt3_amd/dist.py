@@ -86,9 +86,10 @@ def init_distributed(n_gpus: int = 1) -> Tuple[int, int, int]:
         if torch.cuda.is_available():
             n_dev = max(1, torch.cuda.device_count())
             if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > n_dev:
-                # several ranks rehearsing on one GPU: the decode GEMM chain (csrc/dec_chain.hip) needs every CU for ITS workgroups
+                # several ranks rehearsing on one GPU: the merged decode kernels (csrc/dec_chain.hip, dec_attn_pair_kernel) need every CU for THEIR workgroups
                 # while it runs, and two of them from different processes can starve each other until both give up
                 os.environ.setdefault("YMT3_NO_GEMM_CHAIN", "1")
+                os.environ.setdefault("YMT3_NO_ATTN_PAIR", "1")
             local_rank %= n_dev
         kw = {}
         if backend == "nccl":
