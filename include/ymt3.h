@@ -141,6 +141,12 @@ int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* stamps, int ca
  * real decode, which lets a counter pass (rocprofv3 --pmc) cover late positions with a short process. */
 int ymt3_debug_decode_start(ymt3_handle h, int step0);
 
+/* Debug hook, gated like the one above: marks the handle as if one of its merged decode kernels (the attention pair / GEMM chain of the
+ * 64-row regime, whose stages wait for each other inside one launch) had given up waiting.  What must follow -- and what the test of
+ * this hook checks -- is what a real abort triggers: the next decode call's ids are all INT32_MIN, and every call after it fails with
+ * YMT3_ERR_HIP.  YMT3_ERR_UNSUPPORTED if the handle does not run those kernels (fewer than 256 CUs, or both switched off). */
+int ymt3_debug_force_stage_abort(ymt3_handle h);
+
 /* Unit-test hooks: C = A(bf16 MxK) * W^T(bf16 NxK), f32 out; runs the encoder GEMM kernel. */
 int ymt3_test_gemm(ymt3_handle h, const void* a_dev, const void* w_dev, float* c_dev, int M, int N, int K, void* stream);
 

@@ -709,6 +709,27 @@ def test_decode_start_debug_hook_is_gated_and_one_shot(small, monkeypatch):
     m.close()
 
 
+def test_a_stage_abort_poisons_the_ids_and_the_handle_refuses_further_work(small, monkeypatch):
+    """The merged decode kernels bound every spin (50 ms) behind a sticky abort word.  What an abort must trigger, checked through the
+    gated debug hook that raises the word: the call's ids are all INT32_MIN (never plausible ids), and the handle refuses every call after."""
+    from yourmt3_amd import _lib
+    assert small._lib.ymt3_debug_force_stage_abort(small._handle) == 4                    # YMT3_ERR_UNSUPPORTED on a normal handle
+    monkeypatch.setenv("YMT3_DEBUG_HOOKS", "1")
+    m = _model(SMALL)
+    monkeypatch.delenv("YMT3_DEBUG_HOOKS")
+    a = O.synthetic_audio(2, SMALL).cuda()
+    ok = m.inference(a, max_token_length=8)
+    assert int(ok.min()) >= 0
+    _lib.check(m._lib.ymt3_debug_force_stage_abort(m._handle))
+    bad = m.inference(a, max_token_length=8)
+    assert bool((bad == torch.iinfo(torch.int32).min).all())
+    with pytest.raises(_lib.YMT3Error, match="gave up waiting"):
+        m.inference(a, max_token_length=8)
+    with pytest.raises(_lib.YMT3Error):
+        m.logmel(a)
+    m.close()
+
+
 def test_step_stamps_hook(small, monkeypatch):
     from yourmt3_amd._lib import YMT3Error
     with pytest.raises(YMT3Error):

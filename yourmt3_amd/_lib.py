@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("YMT3_LIB", os.path.join(_HERE, "libymt3_hip.so"))
 # every symbol include/ymt3.h declares (tests/test_cpu_host.py::test_library_builds_loads_and_exports_every_header_symbol checks the header against this list)
 SYMBOLS = [
     "ymt3_abi_version", "ymt3_last_error", "ymt3_create", "ymt3_destroy", "ymt3_device_bytes",
-    "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm", "ymt3_profile_decode", "ymt3_debug_decode_start", "ymt3_set_early_stop", "ymt3_last_decode_steps",
+    "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm", "ymt3_profile_decode", "ymt3_debug_decode_start", "ymt3_debug_force_stage_abort", "ymt3_set_early_stop", "ymt3_last_decode_steps",
     "ymt3_ingest_plan", "ymt3_ingest", "ymt3_transcribe_stream", "ymt3_debug_step_stamps", "ymt3_debug_kernel_stamps",
 ]
 
@@ -57,6 +57,8 @@ def load() -> ctypes.CDLL:
     lib.ymt3_profile_decode.restype = i32
     lib.ymt3_debug_decode_start.argtypes = [vp, i32]
     lib.ymt3_debug_decode_start.restype = i32
+    lib.ymt3_debug_force_stage_abort.argtypes = [vp]
+    lib.ymt3_debug_force_stage_abort.restype = i32
     lib.ymt3_last_decode_steps.argtypes = [vp]
     lib.ymt3_last_decode_steps.restype = i32
     lib.ymt3_set_early_stop.argtypes = [vp, i32]

@@ -107,6 +107,7 @@ struct ymt3_ctx {
     unsigned* chain_sync = nullptr;         // [CHAIN_SYNC_WORDS] device: the chain kernel's arrival counters + sticky abort word
     unsigned* chain_host_abort = nullptr;   // pinned: set by the chain kernel together with the abort word; checked at every call
     bool chain_used = false;                // the last captured / launched step contains chain launches
+    bool forced_abort = false;              // ymt3_debug_force_stage_abort: raise the host word after the next decode call, as a kernel would during it
     bool attn_pair = true;                  // a layer's self- and cross-attention as one launch (decode.hip: dec_attn_pair_kernel; YMT3_NO_ATTN_PAIR=1: two)
     unsigned* pair_rows = nullptr;          // [maxR <= 64][2] counter lines of that kernel (zero between launches)
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
@@ -897,6 +898,7 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
     }
     // a GEMM-chain launch that gave up on a stage (dec_chain.hip) must not leave plausible ids behind
     if (h->chain_used) LAUNCH(launch_chain_poison(h->chain_sync, tokens, (long long)R * n_steps, s));
+    if (h->forced_abort && h->chain_host_abort) { *h->chain_host_abort = 1u; h->forced_abort = false; }
     HIP_TRY(hipGetLastError());
     return YMT3_OK;
 }
@@ -1101,6 +1103,20 @@ extern "C" int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* sta
     // the caller's capacity decides how much of the kernel's slot comes back (the GEMM chain keeps stage marks behind its [grid][2] stamps)
     const size_t n_wgs = capacity_wgs < STAMP_WGS ? (size_t)capacity_wgs : (size_t)STAMP_WGS;
     HIP_TRY(hipMemcpy(stamps, h->stamp_buf + (size_t)kernel * STAMP_WGS * 2, n_wgs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_debug_force_stage_abort(ymt3_handle h) {
+    if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (!h->debug_hooks) FAIL(YMT3_ERR_UNSUPPORTED, "debug hooks are accepted only by a handle created with YMT3_DEBUG_HOOKS=1 in the environment");
+    if (!h->chain_sync || !h->chain_host_abort) FAIL(YMT3_ERR_UNSUPPORTED, "this handle does not run the merged decode kernels");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const unsigned one = 1u;
+    // the device word now (what the kernels and the poison pass look at); the host word is what a kernel would set with it --
+    // left for the poison pass's caller to observe: set it only after the next decode call, as the kernel would during that call
+    HIP_TRY(hipMemcpy(h->chain_sync + CHAIN_ABORT_WORD, &one, sizeof(one), hipMemcpyHostToDevice));
+    h->forced_abort = true;
     return YMT3_OK;
 }
 
