@@ -368,6 +368,14 @@ int init_chain_kernels() {
     return rc ? -2 : 0;
 }
 
+// the chain's 256 workgroups must all be resident at once: at least one per CU at its LDS / register footprint
+bool dec_chain_fits(int n_cus) {
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, dec_chain_kernel<DG_NORM_QKV_CACHE>, 512, CHAIN_LDS) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, dec_chain_kernel<DG_NORM_LOGITS>, 512, CHAIN_LDS) != hipSuccess) return false;
+    return (long long)(a < b ? a : b) * n_cus >= 256;
+}
+
 // 0 = launched; negative = this shape is not the chain's (the caller launches the four GEMMs instead)
 int launch_dec_chain(const ChainArgs& c, hipStream_t stream) {
     if (c.R <= 0) return 0;

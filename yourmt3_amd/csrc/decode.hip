@@ -1184,6 +1184,13 @@ int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t strea
     return 0;
 }
 
+// the attention pair's 8 x R <= 512 workgroups must all be resident at once: two per CU at its LDS / register footprint
+bool dec_attention_pair_fits(int n_cus) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dec_attn_pair_kernel, 512, WO_LDS_BYTES) != hipSuccess) return false;
+    return (long long)n * n_cus >= 512;
+}
+
 // self-attention (folded O-projection) + fused cross-attention of one layer as one launch; < 0: not this kernel's shape
 int launch_dec_attention_pair(const DecAttnArgs& a, const DecAttnArgs& b, unsigned* pair_rows, unsigned* abort_word, unsigned* host_abort,
                               hipStream_t stream) {

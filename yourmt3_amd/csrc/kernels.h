@@ -145,6 +145,8 @@ constexpr int CHAIN_COUNTERS = 3 * 4 * 8;
 constexpr int CHAIN_ABORT_WORD = CHAIN_COUNTERS * CHAIN_LINE;
 constexpr int CHAIN_SYNC_WORDS = (CHAIN_COUNTERS + 1) * CHAIN_LINE;
 int init_chain_kernels();
+bool dec_chain_fits(int n_cus);                 // occupancy x CUs covers the chain's grid (all its workgroups wait for each other)
+bool dec_attention_pair_fits(int n_cus);        // the same for the attention pair at 64 rows
 int launch_dec_chain(const ChainArgs& c, hipStream_t stream);       // 0 launched, < 0: not this kernel's shape
 int launch_chain_poison(const unsigned* sync, int32_t* tokens, long long n, hipStream_t stream);   // tokens = INT32_MIN if the chain aborted
 

@@ -346,7 +346,10 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     {   // the GEMM chain needs every workgroup of its grid resident at once: one 143 KB-LDS workgroup per CU, 256 CUs
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-        if (prop.multiProcessorCount < 256 || init_chain_kernels()) c->gemm_chain = c->attn_pair = false;
+        if (init_chain_kernels()) c->gemm_chain = c->attn_pair = false;
+        // every workgroup of a merged kernel's grid must be resident at once: ask the runtime what fits (256 CUs on an MI355X)
+        if (c->gemm_chain && !dec_chain_fits(prop.multiProcessorCount)) c->gemm_chain = false;
+        if (c->attn_pair && !dec_attention_pair_fits(prop.multiProcessorCount)) c->attn_pair = false;
         if (c->gemm_chain || c->attn_pair) {
             if (dev_alloc(c, (void**)&c->chain_sync, CHAIN_SYNC_WORDS * sizeof(unsigned))) return YMT3_ERR_HIP;
             HIP_TRY(hipMemset(c->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
