@@ -1,0 +1,76 @@
+"""Contracts between hand-counted `s_waitcnt` values and what hipcc actually emits (CPU test: cross-compiles csrc/decode.hip to gfx950
+assembly, no GPU needed).
+
+dec_attn_pair_kernel signals a row after `s_waitcnt vmcnt(10)`: the self-attention half's agent-scope partial stores must be older than
+EXACTLY the ten loads issued after them (8 x wq, the residual element, the gain element), with no other vector-memory operation in
+between -- vector-memory operations retire in issue order, so that wait is the stores' acknowledgement without waiting for anything
+younger.  If a compiler change reorders, merges or splits those operations, the count is wrong and a row could be signalled before its
+partials have left: this test fails first."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+@pytest.fixture(scope="module")
+def decode_asm(tmp_path_factory):
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    from yourmt3_amd import build as B
+    out = tmp_path_factory.mktemp("isa") / "decode.s"
+    flags = [f for f in B.FLAGS if f not in ("-fPIC",)]
+    cmd = [hipcc] + flags + ["-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "yourmt3_amd", "csrc", "decode.hip"),
+                             "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    return out.read_text()
+
+
+def _kernel_body(asm: str, name: str) -> list:
+    m = re.search(r"^(_Z\w*" + name + r"\w*):[^\n]*\n(.*?)\n\s*s_endpgm", asm, re.S | re.M)
+    assert m, f"kernel {name} not found in the assembly"
+    return [l.strip() for l in m.group(2).splitlines() if l.strip() and not l.strip().startswith(";")]
+
+
+VMEM = re.compile(r"^(global_|buffer_|flat_|scratch_)")
+
+
+def test_attention_pair_signals_after_exactly_its_ten_loads(decode_asm):
+    body = _kernel_body(decode_asm, "dec_attn_pair_kernel")
+    stores = [i for i, l in enumerate(body) if l.startswith("buffer_store_dwordx4") and " sc1" in l]
+    assert len(stores) == 4, "the O-projection partial leaves as four 16-byte agent-scope stores per lane"
+    waits = [i for i, l in enumerate(body) if l.startswith("s_waitcnt vmcnt(10)") and i > stores[-1]]
+    assert waits, "the hand-off waits with vmcnt(10)"
+    between = [l for l in body[stores[-1] + 1:waits[0]] if VMEM.match(l)]
+    # (a measurement-only stamp store sits behind a branch on the stamp pointer: older than the loads, covered by the same wait)
+    loads = [l for l in between if l.startswith("global_load")]
+    others = [l for l in between if not l.startswith("global_load") and not l.startswith("global_store_dwordx2")]
+    assert len(loads) == 10 and not others, (loads, others)
+    # the first vector-memory operation after the wait is the row's arrival (the atomic add), not a load that could have been counted
+    after = [l for l in body[waits[0] + 1:] if VMEM.match(l)]
+    assert after[0].startswith("global_atomic_add"), after[:3]
+
+
+def test_attention_pair_stays_within_two_workgroups_per_cu(decode_asm):
+    """512 workgroups of 512 threads must all be resident on 256 CUs: <= 128 VGPRs (4 waves per SIMD), no scratch."""
+    m = re.search(r"\.name:\s+\S*dec_attn_pair_kernel\S*\n(.*?)\.wavefront_size", decode_asm, re.S)
+    assert m
+    meta = m.group(1)
+    vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+    spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
+    k = re.search(r"\.amdhsa_kernel \S*dec_attn_pair_kernel\S*\n(.*?)\.end_amdhsa_kernel", decode_asm, re.S)
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", k.group(1)).group(1))
+    assert vgpr <= 128 and spill == 0 and scratch == 0, (vgpr, spill, scratch)
+    assert lds + 65536 <= 80 * 1024, lds          # static + the 64 KB of wo: two per 160 KB CU
