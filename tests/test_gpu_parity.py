@@ -710,7 +710,7 @@ def test_decode_start_debug_hook_is_gated_and_one_shot(small, monkeypatch):
 
 
 def test_a_stage_abort_poisons_the_ids_and_the_handle_refuses_further_work(small, monkeypatch):
-    """The merged decode kernels bound every spin (50 ms) behind a sticky abort word.  What an abort must trigger, checked through the
+    """The merged decode kernels bound every spin (1 s) behind a sticky abort word.  What an abort must trigger, checked through the
     gated debug hook that raises the word: the call's ids are all INT32_MIN (never plausible ids), and the handle refuses every call after."""
     from yourmt3_amd import _lib
     assert small._lib.ymt3_debug_force_stage_abort(small._handle) == 4                    # YMT3_ERR_UNSUPPORTED on a normal handle

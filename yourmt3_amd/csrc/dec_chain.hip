@@ -25,7 +25,7 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int DKV = 64;
 constexpr int AGENT = 16;                       // buffer-instruction cache policy bit 4 = sc1 (agent scope) on gfx94x / gfx950
-constexpr unsigned long long SPIN_LIMIT = 5000000ull;   // 50 ms of the 100 MHz wall clock
+constexpr unsigned long long SPIN_LIMIT = 100000000ull;   // 1 s of the 100 MHz wall clock (a stage hands over in ~1 us; this only has to outlast a time-sliced GPU)
 
 #define CH_STAMP_IN(c) do { if ((c).stamp && threadIdx.x == 0) (c).stamp[2 * blockIdx.x] = wall_clock64(); } while (0)
 #define CH_MARK(c, k) do { if ((c).stamp && threadIdx.x == 0) (c).stamp[512 + 8 * blockIdx.x + (k)] = wall_clock64(); } while (0)   // measurement: stage marks

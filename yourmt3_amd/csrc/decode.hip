@@ -533,7 +533,7 @@ __device__ __forceinline__ void pair_wait(const PairSync& ps, int r) {
             if ((++polls & 63u) == 0u) {
                 const unsigned long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
-                if (__hip_atomic_load(ps.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > 5000000ull) {      // 50 ms
+                if (__hip_atomic_load(ps.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > 100000000ull) {      // 1 s
                     __hip_atomic_store(ps.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (ps.host_abort) __hip_atomic_store(ps.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     ok = false;

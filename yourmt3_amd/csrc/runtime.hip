@@ -439,7 +439,7 @@ static int check_call(ymt3_handle h, int B) {
     if (B < 0 || B > h->maxB) FAIL(YMT3_ERR_ARG, "B=%d outside [0, max_batch=%d]", B, h->maxB);
     HIP_TRY(hipSetDevice(h->device));
     if (h->chain_host_abort && *static_cast<volatile unsigned*>(h->chain_host_abort))
-        FAIL(YMT3_ERR_HIP, "a decode GEMM-chain launch gave up waiting for one of its stages (> 50 ms; were all 256 CUs available to it?): the token ids "
+        FAIL(YMT3_ERR_HIP, "a decode GEMM-chain launch gave up waiting for one of its stages (> 1 s; were all 256 CUs available to it?): the token ids "
                            "of that call were overwritten with INT32_MIN and this handle refuses further work (YMT3_NO_GEMM_CHAIN=1 avoids the kernel)");
     return 0;
 }
