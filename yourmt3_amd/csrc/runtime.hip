@@ -100,6 +100,7 @@ struct ymt3_ctx {
     hipEvent_t fork_ev = nullptr, join_ev[8] = {};
     std::map<long, StepGraph> step_graphs;  // keyed by (B, n_chains_used, chain)
     bool use_graph = true;
+    int graph_steps = 16;                   // decode steps per replayed graph (YMT3_GRAPH_STEPS): a graph launch costs ~7 us of stream time on top of its kernels
     bool fuse_q = true;                     // cross-attention computes its own query projection
     bool moe_fold_combine = true;           // MoE: h += y0 + y1 is done by the next norm GEMM's prologue (YMT3_MOE_COMBINE_LAUNCH=1: own launch)
     bool fold_o = true;                     // self-attention ends with its head's O-projection partial; no separate O-projection launch
@@ -379,6 +380,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     c->debug_hooks = dh && dh[0] == '1';
     const char* ng = getenv("YMT3_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
+    if (const char* gs = getenv("YMT3_GRAPH_STEPS")) { const int v = atoi(gs); if (v >= 1 && v <= 64) c->graph_steps = v; }
     const char* nf = getenv("YMT3_NO_FUSEQ");
     c->fuse_q = !(nf && nf[0] == '1');
     const char* mcl = getenv("YMT3_MOE_COMBINE_LAUNCH");
@@ -868,7 +870,25 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
             h->last_steps = t;
             LAUNCH(launch_pad_tail(tokens, 0, R, n_steps, t, k.pad_id, s));
         } else if (n_chains == 1) {
-            for (int t = 0; t < n_steps; ++t) HIP_TRY(hipGraphLaunch(exec[0], s));
+            // graph_steps consecutive steps are ONE replayed graph (every kernel reads the position from device memory, so a graph of G
+            // steps is the step's kernels G times): the boundary between two graph launches costs ~7 us of stream time that a kernel
+            // boundary inside a graph does not (eager launches ran 2.9 % faster than one-step graphs, profiles/r02_graph_steps.txt)
+            const int G = h->graph_steps;
+            int t = 0;
+            if (G > 1 && n_steps >= G) {
+                StepGraph& mg = h->step_graphs[(((long)B * 16 + 1) * 16) | (1L << 40) | ((long)G << 32)];
+                if (!mg.exec) {
+                    HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+                    int rc = 0;
+                    for (int i = 0; i < G && !rc; ++i) rc = launch_step(h, B, 0, R, h->shared, h->cap_stream);
+                    hipError_t e = hipStreamEndCapture(h->cap_stream, &mg.graph);
+                    if (rc) return rc;
+                    if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+                    HIP_TRY(hipGraphInstantiate(&mg.exec, mg.graph, nullptr, nullptr, 0));
+                }
+                for (; t + G <= n_steps; t += G) HIP_TRY(hipGraphLaunch(mg.exec, s));
+            }
+            for (; t < n_steps; ++t) HIP_TRY(hipGraphLaunch(exec[0], s));
         } else {
             // fork: every chain stream waits for the cross-KV GEMM + init on the caller's stream
             HIP_TRY(hipEventRecord(h->fork_ev, s));
@@ -968,11 +988,15 @@ extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int
     HIP_TRY(hipMemsetAsync(h->row_out, 0, (size_t)R * sizeof(long long), s));
 
     hipGraphExec_t exec = nullptr;
+    // one replayed graph per round of `interval` steps when that is at most 64 steps (a graph launch costs ~7 us of stream time on
+    // top of its kernels, see decode_impl); else one per step
+    const int per_graph = interval <= 64 ? interval : 1;
     if (h->use_graph) {
-        StepGraph& sg = h->step_graphs[((long)slots * 16 + 15) * 16];      // 15: slot-mode graph of `slots` segments
+        StepGraph& sg = h->step_graphs[(((long)slots * 16 + 15) * 16) | ((long)per_graph << 32)];      // 15: slot-mode graph of `slots` segments
         if (!sg.exec) {
             HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rcs = launch_step(h, slots, 0, R, h->shared, h->cap_stream);
+            int rcs = 0;
+            for (int i = 0; i < per_graph && !rcs; ++i) rcs = launch_step(h, slots, 0, R, h->shared, h->cap_stream);
             hipError_t e = hipStreamEndCapture(h->cap_stream, &sg.graph);
             if (rcs) return rcs;
             if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -1006,7 +1030,7 @@ extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int
     for (long round = 0; live > 0; ++round) {
         h->last_steps += interval;
         if (round > max_rounds) FAIL(YMT3_ERR_HIP, "slot scheduler made no progress (%d live, %d admitted of %d)", live, next, n_segments);
-        for (int i = 0; i < interval; ++i) {
+        for (int i = 0; i < interval; i += exec ? per_graph : 1) {
             if (exec) HIP_TRY(hipGraphLaunch(exec, s));
             else { int rcs = launch_step(h, slots, 0, R, h->shared, s); if (rcs) return rcs; }
         }
