@@ -32,7 +32,7 @@ print(f"step: {rows[-1][5] - rows[0][2]:.2f} us = spans {tot_span:.2f} + gaps {t
 import numpy as np
 names = [r[0] for r in rows]
 nth = lambda name, n: [i for i, x in enumerate(names) if x == name][n]
-for k in ((nth("self_attn", 3), nth("cross_attn", 3)) if B == 64 else ()):
+for k in ((nth("self_attn", 3), nth("cross_attn", 3)) if B == 64 and "self_attn" in names else ()):   # (the attention pair has its own marks: gpu_pair_marks.py)
     name, grid = rows[k][0], rows[k][1]
     st = m.kernel_stamps(k, grid).astype(np.int64)
     st = st[st[:, 0] > 0]                                   # a launcher may use fewer workgroups than the slot reserves
