@@ -1,3 +1,5 @@
+#!/bin/bash
+# MoE decoder (configs[4]) with the attention pair on / off: parity tests first, then interleaved timing
 set -o pipefail
 timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "moe or round_1 or config_4" 2>&1 | tail -3 || exit 1
 cat > /tmp/cfg_ab.py <<'PY'
