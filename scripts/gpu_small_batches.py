@@ -1,5 +1,5 @@
 """Latency of small batches (BASELINE configs[0]'s shape on the GPU path: one 2.048 s segment, 1024 tokens) and the
-batch-size curve at the configs[1] shapes.  Output: JSON (profiles/r01_small_batches.json)."""
+batch-size curve at the configs[1] shapes.  Output: JSON (profiles/r01_small_batches.json, r02_small_batches.json)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
