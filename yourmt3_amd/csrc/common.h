@@ -35,6 +35,24 @@ __device__ __forceinline__ float add_sep(float a, float b) {
     return a + b;
 }
 
+// Cross-lane moves inside a 16-lane row by DPP (no LDS crossbar round trip: a ds_bpermute costs ~100 cycles, and a chain of them sits
+// on the critical path of every latency-bound decode kernel).
+#define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+// the same restricted to the 16-lane rows in `rows` (bit r = row r); the other rows read 0.0f
+#define DPP_ROWS(v, ctrl, rows) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xF, false))
+__device__ __forceinline__ float add_xor1(float v) { return v + DPP_F(v, 0xB1); }     // quad_perm [1,0,3,2]: + lane ^ 1
+__device__ __forceinline__ float add_xor2(float v) { return v + DPP_F(v, 0x4E); }     // quad_perm [2,3,0,1]: + lane ^ 2
+__device__ __forceinline__ float add_xor8(float v) { return v + DPP_F(v, 0x128); }    // row_ror:8: + lane ^ 8 within the row of 16
+// v + lanes ^1, ^2, ^4: bit for bit `v += shfl_xor(v, 1); v += shfl_xor(v, 2); v += shfl_xor(v, 4)` -- the first two steps add the same
+// lane pairs; after them the four lanes of a quad hold one value, so the third step may read ANY lane of the other quad
+// (row_half_mirror: lane 7 - l) for what lane ^ 4 holds
+__device__ __forceinline__ float sum8(float v) {
+    v = add_xor1(v);
+    v = add_xor2(v);
+    v += DPP_F(v, 0x141);
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -137,9 +137,7 @@ __device__ __forceinline__ float2 resid_out(float2 hold, float2 s, float* pH, fl
     }
     // two products and a sum, as dec_gemm_kernel's epilogue compiles (v_pk_mul_f32, v_add_f32): hipcc would contract this copy into an fma
     float q = add_sep(mul_sep(o.x, o.x), mul_sep(o.y, o.y));
-    q += __shfl_xor(q, 1, 64);
-    q += __shfl_xor(q, 2, 64);
-    q += __shfl_xor(q, 4, 64);
+    q = sum8(q);
     if (live && (threadIdx.x & 7) == 0) st_agent(pSsq + (size_t)nt_idx * ssq_stride + m, q);
     return o;
 }
@@ -188,9 +186,7 @@ __device__ __forceinline__ void norm_tile(const ChainArgs& c, const float* pH, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) ss += ld_agent(c.ssq + (size_t)((tid & 7) * 4 + j) * c.ssq_stride + mm);
     }
-    ss += __shfl_xor(ss, 1, 64);
-    ss += __shfl_xor(ss, 2, 64);
-    ss += __shfl_xor(ss, 4, 64);
+    ss = sum8(ss);
     if (tid < 16 * 8 && (tid & 7) == 0) sscale[tid >> 3] = rsqrtf(ss / 512.f + c.eps);
     __syncthreads();
 #pragma unroll

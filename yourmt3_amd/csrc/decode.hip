@@ -174,10 +174,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xv[i][e] += y0v[i][e] + y1v[i][e];          // h + (y0 + y1), as the combine kernel summed
                     float q = (xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1]) + (xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3]);
-                    q += __shfl_xor(q, 1, 64);                       // the LPRX = 16 lanes that hold this row's K-slice
-                    q += __shfl_xor(q, 2, 64);
-                    q += __shfl_xor(q, 4, 64);
-                    q += __shfl_xor(q, 8, 64);
+                    q = add_xor8(sum8(q));                           // the LPRX = 16 lanes that hold this row's K-slice (lanes ^1, ^2, ^4, ^8)
                     if ((lane % LPRX) == 0) wpart[wave * ROWS + row] = q;
                     if constexpr (MODE == DG_NORM_QKV_CACHE) {       // (lm_head is the last reader of the stream: nothing to publish)
                         if (nt_idx == 0 && m0 + row < m_end)         // column tile 0 publishes the completed residual row
@@ -185,9 +182,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
                     }
                 }
             } else {
-                ss += __shfl_xor(ss, 1, 64);
-                ss += __shfl_xor(ss, 2, 64);
-                ss += __shfl_xor(ss, 4, 64);
+                ss = sum8(ss);
                 if (tid < ROWS * 8 && (tid & 7) == 0) sscale[tid >> 3] = rsqrtf(ss / (float)K + a.eps);
             }
 #pragma unroll
@@ -277,9 +272,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
         }
         // this tile's share of sum(h^2) for the next norm
         float q = o.x * o.x + o.y * o.y;
-        q += __shfl_xor(q, 1, 64);
-        q += __shfl_xor(q, 2, 64);
-        q += __shfl_xor(q, 4, 64);
+        q = sum8(q);
         if (live && (tid & 7) == 0) pSsq[(size_t)nt_idx * ssq_stride + m] = q;
     } else if constexpr (MODE == DG_NORM_LOGITS) {
         if (live) *reinterpret_cast<float2*>(pOut + (size_t)m * N + n) = s;
@@ -403,8 +396,7 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < SSQ_TILES / 4; ++j) ss += pSsq[(size_t)((tid & 3) * (SSQ_TILES / 4) + j) * ssq_stride + mm];
-            ss += __shfl_xor(ss, 1, 64);
-            ss += __shfl_xor(ss, 2, 64);
+            ss = add_xor2(add_xor1(ss));
             if ((tid & 3) == 0) sscale[row] = rsqrtf(ss / (float)K + a.eps);
         }
         __syncthreads();
@@ -486,15 +478,7 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// sum over the 8 lanes that share one key (lane & 7 = 16-byte chunk of the 128-byte row): DPP moves,
-// no LDS crossbar (ds_bpermute) in the inner loop
-#define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
-__device__ __forceinline__ float sum8(float v) {
-    v += DPP_F(v, 0xB1);     // quad_perm [1,0,3,2]  : lane ^ 1
-    v += DPP_F(v, 0x4E);     // quad_perm [2,3,0,1]  : lane ^ 2
-    v += DPP_F(v, 0x141);    // row_half_mirror      : lane -> 7 - lane within its 8 (other quad, already summed)
-    return v;
-}
+// (sum8: the sum over the 8 lanes that share one key -- lane & 7 = 16-byte chunk of the 128-byte row -- by DPP moves: common.h)
 
 // FUSEQ (cross-attention only): the query projection of the block,  q = R( R(rmsnorm(h_r) * gain) . Wq[head]^T ),  is
 // computed inside this kernel instead of by a separate skinny GEMM launch.  Its operands (64 weight rows of this
@@ -761,10 +745,10 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
             for (int w = 1; w < 8; ++w) sp += pv[w];
             x_v += sp;
             float q2 = mul_sep(x_v, x_v);
-            q2 = add_sep(q2, __shfl_xor(q2, 1, 64));
-            q2 = add_sep(q2, __shfl_xor(q2, 2, 64));
-            q2 = add_sep(q2, __shfl_xor(q2, 4, 64));
-            q2 = add_sep(q2, __shfl_xor(q2, 8, 64));
+            q2 = add_sep(q2, DPP_F(q2, 0xB1));        // lane ^ 1
+            q2 = add_sep(q2, DPP_F(q2, 0x4E));        // lane ^ 2
+            q2 = add_sep(q2, DPP_F(q2, 0x141));       // row_half_mirror: a lane of the other quad, which holds what lane ^ 4 holds
+            q2 = add_sep(q2, DPP_F(q2, 0x128));       // row_ror:8 = lane ^ 8 within the row of 16
             if ((tid & 15) == 0) s_tile[tid >> 4] = q2;
             __syncthreads();
             ss = tid < SSQ_TILES ? s_tile[tid] : 0.f;
@@ -778,6 +762,7 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
         float xn[8];
         *reinterpret_cast<float4*>(xn) = *reinterpret_cast<const float4*>(xs + lane * 8);
         *reinterpret_cast<float4*>(xn + 4) = *reinterpret_cast<const float4*>(xs + lane * 8 + 4);
+        float dd[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             float d = 0.f;
@@ -788,10 +773,19 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
             }
             d = sum8(d);
             d += DPP_F(d, 0x128);                                 // row_ror:8 -> lane ^ 8 within the row of 16
-            d += __shfl_xor(d, 16, 64);
-            d += __shfl_xor(d, 32, 64);
-            if (lane == jj) qs[wave * 8 + jj] = f2bf(d);
+            dd[jj] = d;
         }
+        // Every lane of a 16-lane row now holds its row's sum r0..r3.  The wave total is (r0 + r1) + (r2 + r3) -- what two butterfly steps
+        // (lane ^ 16, lane ^ 32) gave every lane, through the LDS crossbar, sixteen dependent round trips for the eight outputs (0.8 us on
+        // the critical path).  Row broadcasts (DPP) add the same pairs with the operands swapped -- IEEE addition commutes, same bits --
+        // and leave the total in row 3.
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) dd[jj] += DPP_ROWS(dd[jj], 0x142, 0xA);       // row_bcast:15 -> rows 1 and 3: r1 + r0, r3 + r2
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) dd[jj] += DPP_ROWS(dd[jj], 0x143, 0xC);       // row_bcast:31 -> row 3: (r3 + r2) + (r1 + r0)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            if (lane == 56 + jj) qs[wave * 8 + jj] = f2bf(dd[jj]);
         __syncthreads();
         qp = *reinterpret_cast<const u32x4*>(qs + sub * 8);
         // the block loaded above, then the remaining ones
@@ -942,14 +936,25 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
         const float v = row[i];
         if (v > bv) { bv = v; bi = i; }       // ascending i: the first maximum is kept
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(bv, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    // wave-wide (max value, lowest index): the selection is commutative and associative, so any reduction order gives the same pair.
+    // Rotations inside the 16-lane rows, then row broadcasts (all DPP; twelve dependent ds_bpermute round trips before): row 3 ends up
+    // with the wave's pair.
+#define ARGMAX_TAKE(ctrl, rows, cond)                                                                                      \
+    do {                                                                                                                  \
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bv), (ctrl), (rows), 0xF, false)); \
+        const int oi = __builtin_amdgcn_update_dpp(0, bi, (ctrl), (rows), 0xF, false);                                    \
+        if ((cond) && (ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }                                           \
+    } while (0)
+    ARGMAX_TAKE(0x128, 0xF, true);            // row_ror:8
+    ARGMAX_TAKE(0x124, 0xF, true);            // row_ror:4
+    ARGMAX_TAKE(0x122, 0xF, true);            // row_ror:2
+    ARGMAX_TAKE(0x121, 0xF, true);            // row_ror:1: every lane holds its row's pair
+    ARGMAX_TAKE(0x142, 0xA, (lane & 16) != 0);    // row_bcast:15 -> rows 1 and 3
+    ARGMAX_TAKE(0x143, 0xC, lane >= 32);          // row_bcast:31 -> (rows 2 and) 3
+#undef ARGMAX_TAKE
+    if (lane == 63) { sv[wave] = bv; si[wave] = bi; }
     __syncthreads();
+    if (tid == 0) { bv = sv[0]; bi = si[0]; }      // (the wave's pair sits in its last row)
     if (tid == 0 && pRowPos) {
         // slot mode: this row's own position; a stopped row writes nothing and stays where it is (its slot is refilled
         // by the host), a live one stops after EOS or its n_steps-th token
