@@ -53,9 +53,20 @@ __device__ __forceinline__ float sum8(float v) {
     return v;
 }
 
+// The 64-lane butterfly sum  v += lane^32; += lane^16; += lane^8; += lane^4; += lane^2; += lane^1  with the four in-row steps as DPP
+// moves (every lane receives exactly the lane the shuffle gave it: same operands, same order, same bits).  lane ^ 4 takes two moves:
+// row_shl:4 for the lanes whose bit 2 is clear (banks 0 and 2 read lane + 4), row_shr:4 for the others (banks 1 and 3 read lane - 4).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    v = add_xor8(v);
+    {
+        int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0x5, false);      // row_shl:4 -> banks 0, 2
+        t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, v), 0x114, 0xF, 0xA, false);          // row_shr:4 -> banks 1, 3
+        v += __builtin_bit_cast(float, t);
+    }
+    v = add_xor2(v);
+    v = add_xor1(v);
     return v;
 }
 
