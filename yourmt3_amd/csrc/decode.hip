@@ -751,13 +751,19 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
             q2 = add_sep(q2, DPP_F(q2, 0x128));       // row_ror:8 = lane ^ 8 within the row of 16
             if ((tid & 15) == 0) s_tile[tid >> 4] = q2;
             __syncthreads();
-            ss = tid < SSQ_TILES ? s_tile[tid] : 0.f;
+            ss = lane < SSQ_TILES ? s_tile[lane] : 0.f;              // every wave sums the 32 tiles itself: no broadcast of the scale, one barrier less
         }
         // norm scale (fixed-order tree over the 32 partials), normed row -> LDS as bf16-rounded floats
         ss = wave_sum(ss);
-        if (tid == 0) s_scale = rsqrtf(ss / 512.f + a.eps);
-        __syncthreads();
-        xs[tid] = bf2f(f2bf(x_v * s_scale * g_v));
+        float scale;
+        if constexpr (OP) {
+            scale = rsqrtf(ss / 512.f + a.eps);
+        } else {                                                     // the carried partials were loaded by the first 32 threads only
+            if (tid == 0) s_scale = rsqrtf(ss / 512.f + a.eps);
+            __syncthreads();
+            scale = s_scale;
+        }
+        xs[tid] = bf2f(f2bf(x_v * scale * g_v));
         __syncthreads();
         float xn[8];
         *reinterpret_cast<float4*>(xn) = *reinterpret_cast<const float4*>(xs + lane * 8);
