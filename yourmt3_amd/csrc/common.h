@@ -53,12 +53,32 @@ __device__ __forceinline__ float sum8(float v) {
     return v;
 }
 
-// The 64-lane butterfly sum  v += lane^32; += lane^16; += lane^8; += lane^4; += lane^2; += lane^1  with the four in-row steps as DPP
-// moves (every lane receives exactly the lane the shuffle gave it: same operands, same order, same bits).  lane ^ 4 takes two moves:
+// The value of lane ^ 16 / lane ^ 32 at VALU speed: gfx950's v_permlane16_swap / v_permlane32_swap with both operands the same register
+// return (tools/permlane_probe.cpp, checked on hardware against __shfl_xor) { [r0 r0 r2 r2], [r1 r1 r3 r3] } over the 16-lane rows and
+// { [lo lo], [hi hi] } over the 32-lane halves.  One-dimensional workgroups (threadIdx.x & 63 is the lane), all lanes active.
+__device__ __forceinline__ float lane_xor16(float v) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 16u) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32u) ? r[0] : r[1]);
+}
+// lane ^ off for off = 8, 16, 32 (a compile-time constant after unrolling) without the LDS crossbar
+__device__ __forceinline__ float lane_xor(float v, int off) {
+    if (off == 8) return DPP_F(v, 0x128);
+    if (off == 16) return lane_xor16(v);
+    return lane_xor32(v);
+}
+
+// The 64-lane butterfly sum  v += lane^32; += lane^16; += lane^8; += lane^4; += lane^2; += lane^1  with every step as a register move
+// (every lane receives exactly the lane the shuffle gave it: same operands, same order, same bits).  lane ^ 4 takes two DPP moves:
 // row_shl:4 for the lanes whose bit 2 is clear (banks 0 and 2 read lane + 4), row_shr:4 for the others (banks 1 and 3 read lane - 4).
 __device__ __forceinline__ float wave_sum(float v) {
-    v += __shfl_xor(v, 32, 64);
-    v += __shfl_xor(v, 16, 64);
+    v += lane_xor32(v);
+    v += lane_xor16(v);
     v = add_xor8(v);
     {
         int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0x5, false);      // row_shl:4 -> banks 0, 2

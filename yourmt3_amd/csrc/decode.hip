@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
                 *dst = o;
                 q = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
             }
-            q += __shfl_xor(q, 16, 64);           // the four lanes (g) that hold this row's 16 columns of the tile
-            q += __shfl_xor(q, 32, 64);
+            q += lane_xor16(q);                   // the four lanes (g) that hold this row's 16 columns of the tile
+            q += lane_xor32(q);
             if (live && g == 0) pSsq[(size_t)(n0 / 16 + wave) * ssq_stride + m] = q;
         } else if constexpr (MODE == DG_NORM_LOGITS) {
             if (live) *reinterpret_cast<float4*>(pOut + (size_t)m * N + n) = make_float4(s[0], s[1], s[2], s[3]);
@@ -805,12 +805,12 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
     // merge the 8 key groups of the wave (lanes with equal `sub`)
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) {
-        const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
+        const float mo = lane_xor(m, off), lo = lane_xor(l, off);      // (register moves, not the LDS crossbar: common.h)
         const float mn = fmaxf(m, mo);
         const float sa = __expf(m - mn), sb = __expf(mo - mn);
         l = l * sa + lo * sb;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) acc[d] = acc[d] * sa + __shfl_xor(acc[d], off, 64) * sb;
+        for (int d = 0; d < 8; ++d) acc[d] = acc[d] * sa + lane_xor(acc[d], off) * sb;
         m = mn;
     }
     if (kg == 0) {
