@@ -100,8 +100,8 @@ __global__ __launch_bounds__(enc_attn_threads<T>()) void enc_attn_kernel(const b
             s[kt][r] += sB[key - q + T - 1];
             mx = fmaxf(mx, s[kt][r]);
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, lane_xor16(mx));
+    mx = fmaxf(mx, lane_xor32(mx));
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(enc_attn_threads<T>()) void enc_attn_kernel(const b
             s[kt][r] = e;
             sum += e;
         }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum += lane_xor16(sum);
+    sum += lane_xor32(sum);
 
     // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; k-step = key tiles (2kp, 2kp+1)
     f32x4 o[4];
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(seq_attn_threads<TK>()) void seq_attn_kernel(SeqAtt
                 sc[kt][r] += sB[kt * 16 + 4 * g + r + boff];
                 mx = fmaxf(mx, sc[kt][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, lane_xor16(mx));
+        mx = fmaxf(mx, lane_xor32(mx));
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(seq_attn_threads<TK>()) void seq_attn_kernel(SeqAtt
                 sc[kt][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum += lane_xor16(sum);
+        sum += lane_xor32(sum);
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(const float* __restr
         const int row = tid >> 4, part = tid & 15;
         float ss = 0.f;
         if (row < nc) ss = pSsq[(size_t)(2 * part) * a.ssq_stride + r0 + row] + pSsq[(size_t)(2 * part + 1) * a.ssq_stride + r0 + row];
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        ss = add_xor8(sum8(ss));                 // lanes ^1, ^2, ^4, ^8 by DPP moves (common.h): same pairs, same bits
         if (part == 0) sscale[row] = rsqrtf(ss / 512.f + a.eps);
     }
     __syncthreads();
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, lane_xor16(mx));
+    mx = fmaxf(mx, lane_xor32(mx));
     if (g == 0) smx[wave * 16 + li] = mx;
     __syncthreads();
     const float M = fmaxf(fmaxf(smx[li], smx[16 + li]), fmaxf(smx[32 + li], smx[48 + li]));
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(const float* __restr
             s[kt][r] = e;
             sum += e;
         }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum += lane_xor16(sum);
+    sum += lane_xor32(sum);
     if (g == 0) ssum[wave * 16 + li] = sum;
 
     // --- partial O^T over this wave's keys: k-step = key tiles (2kp, 2kp+1); P as hi + lo bf16 terms
