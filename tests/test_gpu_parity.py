@@ -909,3 +909,23 @@ def test_continuous_batching_equals_lockstep_batches(base):
     # the lock-step path is untouched by a stream call in between
     assert np.array_equal(np.concatenate(m.inference_file(4, audio), 0), ref)
     m.close()
+
+
+def test_token_all_gather_over_rccl_on_one_gpu():
+    """The data path's only collective, through RCCL itself: a one-rank `nccl` process group on this GPU runs
+    dist.all_gather_into_tensor on the int32 device tensor the decode leaves (the builder's box has one GPU, so the ring is trivial;
+    what this checks is that the backend initialises in this image and takes the call exactly as yourmt3_amd.dist makes it)."""
+    import torch.distributed as dist
+    from yourmt3_amd.dist import all_gather_tokens
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        tok = torch.randint(0, 1536, (64, 1, 1024), dtype=torch.int32, device="cuda")
+        out = all_gather_tokens(tok, 1, always_collective=True)
+        torch.cuda.synchronize()
+        assert out.shape == tok.shape and torch.equal(out, tok)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

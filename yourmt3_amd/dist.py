@@ -109,13 +109,14 @@ def shard_sizes(n_segments: int, world: int) -> List[int]:
     return [shard_range(n_segments, r, world)[1] - shard_range(n_segments, r, world)[0] for r in range(world)]
 
 
-def all_gather_tokens(tokens: torch.Tensor, world: int, n_segments: int | None = None) -> torch.Tensor:
+def all_gather_tokens(tokens: torch.Tensor, world: int, n_segments: int | None = None, always_collective: bool = False) -> torch.Tensor:
     """(b_local, K, L) int32 per rank -> (n_segments, K, L) on every rank, in segment order.
 
     Equal shards use one all_gather_into_tensor.  Ragged shards (the tail rank has fewer segments)
-    are padded to the largest shard, gathered, and the padding rows dropped.
+    are padded to the largest shard, gathered, and the padding rows dropped.  A single rank returns its tokens as they are
+    unless `always_collective` (a test's way to run the collective itself -- RCCL on one GPU -- through this code path).
     """
-    if world == 1:
+    if world == 1 and not always_collective:
         return tokens
     b, K, L = tokens.shape
     if n_segments is None:
