@@ -83,10 +83,14 @@ __global__ __launch_bounds__(512) void moe_router_kernel(const float* __restrict
     float best = -3.4e38f, second = -3.4e38f;
     int e0 = 0, e1 = 0;
     const int ne = E < 8 ? E : 8;
-    for (int e = 0; e < ne; ++e) {
-        const float le = __shfl(s, e * 8, 64);
-        if (le > best) { second = best; e1 = e0; best = le; e0 = e; }
-        else if (le > second) { second = le; e1 = e; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        // logit[e] from lane 8e by v_readlane (a scalar broadcast), not eight dependent trips through the LDS crossbar
+        const float le = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), e * 8));
+        if (e < ne) {
+            if (le > best) { second = best; e1 = e0; best = le; e0 = e; }
+            else if (le > second) { second = le; e1 = e; }
+        }
     }
     for (int e = 8; e < E; ++e) {                             // experts 8..15: plain wave-wide dots
         const bf16_t* w = pRouter + (size_t)e * D;
