@@ -16,8 +16,11 @@
  * Conventions
  *   - every pointer named *_dev is DEVICE memory on the handle's GPU, owned by the caller;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all calls are
- *     asynchronous with respect to the host and never synchronise the device (two documented exceptions, both
- *     opt-in: ymt3_set_early_stop and the ymt3_profile_decode measurement hook);
+ *     asynchronous with respect to the host and never synchronise the device.  Exceptions, all documented at their
+ *     declarations: ymt3_transcribe_stream, ymt3_set_early_stop (opt-in), the ymt3_profile_decode / ymt3_debug_* measurement
+ *     hooks, and -- on by default, ymt3_set_abort_recovery(h, 0) turns it off -- the one wait at the END of a decode call
+ *     that ran the merged decode kernels of the 64-row regime (after its last step has been queued; nothing is
+ *     launched behind it unless a kernel gave up);
  *   - the library owns weights, KV caches and scratch inside the handle; nothing is
  *     allocated after ymt3_create();
  *   - return value: 0 = ok, non-zero = error; the message is in ymt3_last_error()
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define YMT3_ABI_VERSION 2
+#define YMT3_ABI_VERSION 3
 
 enum { YMT3_OK = 0, YMT3_ERR_ARG = 1, YMT3_ERR_BLOB = 2, YMT3_ERR_HIP = 3, YMT3_ERR_UNSUPPORTED = 4 };
 enum { YMT3_ENC_T5 = 0, YMT3_ENC_PERCEIVER_TF = 1 };
@@ -93,8 +96,8 @@ int ymt3_decode_greedy(ymt3_handle h, const void* enc_dev, int B, int n_steps, i
 
 /* Opt-in early stop (first step): with eos_id >= 0 and interval > 0, ymt3_decode_greedy /
  * ymt3_transcribe_segments check on the host every `interval` steps whether every row has emitted EOS and stop
- * launching once all have (the remainder of each row is PAD, exactly what the full-length run produces).  This is the
- * ONLY mode in which a call synchronises the stream.  interval = 0 (default) restores the fully asynchronous loop. */
+ * launching once all have (the remainder of each row is PAD, exactly what the full-length run produces).  In this mode the
+ * call synchronises the stream once per interval.  interval = 0 (default) restores the loop that queues every step at once. */
 int ymt3_set_early_stop(ymt3_handle h, int interval);
 
 /* The whole hot path: audio (B, segment_samples) f32 -> token ids (B, n_channels, n_steps) int32. */
@@ -114,6 +117,21 @@ int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int n_segments
 /* Number of decoder steps the last decode call on this handle actually launched (ymt3_decode_greedy,
  * ymt3_transcribe_segments: n_steps unless ymt3_set_early_stop cut it short; ymt3_transcribe_stream: every step of every round). */
 int ymt3_last_decode_steps(ymt3_handle h);
+
+/* The merged decode kernels (up to 64 rows, one channel: a layer's two attentions as one launch, its four skinny GEMMs as one launch)
+ * hand data between workgroups inside a launch and therefore need every workgroup of their grid resident at once; the handle enables
+ * them only where the occupancy query says they fit.  If something else holds CUs while one runs (another process or handle on the
+ * same GPU, a CU mask), a stage can wait in vain: every wait is bounded (1 s), then the kernel raises a sticky abort word and the
+ * launch drains.  What follows is governed by `mode`:
+ *   1 (default): ymt3_decode_greedy / ymt3_transcribe_segments / ymt3_transcribe_stream wait for their own work at the end of the call
+ *      and look at the word.  Raised: the call is run AGAIN through the separate launches (fresh launches in the same process;
+ *      the same arithmetic, bit-identical ids) and the handle stays on them.  The caller sees correct ids, later.
+ *   0: calls stay fully asynchronous.  An aborted call's ids are all INT32_MIN (never plausible ids); the NEXT call on the handle
+ *      notices, waits for the device, and switches to the separate launches before doing its own work.
+ * ymt3_merged_fallbacks: how many times this handle has left the merged kernels that way (0 or 1; it never goes back).
+ * (YMT3_ABORT_RECOVERY=0 in the environment at ymt3_create selects mode 0.) */
+int ymt3_set_abort_recovery(ymt3_handle h, int mode);
+int ymt3_merged_fallbacks(ymt3_handle h);
 
 /* Measurement hook (bench.py `roofline`): decode eagerly (no graph) and bracket every kernel launch of
  * every `stride`-th step (positions stride/2, 3*stride/2, ...) with HIP events on `stream`; synchronises the stream before returning.
@@ -142,9 +160,11 @@ int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* stamps, int ca
 int ymt3_debug_decode_start(ymt3_handle h, int step0);
 
 /* Debug hook, gated like the one above: marks the handle as if one of its merged decode kernels (the attention pair / GEMM chain of the
- * 64-row regime, whose stages wait for each other inside one launch) had given up waiting.  What must follow -- and what the test of
- * this hook checks -- is what a real abort triggers: the next decode call's ids are all INT32_MIN, and every call after it fails with
- * YMT3_ERR_HIP.  YMT3_ERR_UNSUPPORTED if the handle does not run those kernels (fewer than 256 CUs, or both switched off). */
+ * 64-row regime, whose stages wait for each other inside one launch) had given up waiting during the NEXT decode call.  What must
+ * follow -- and what the test of this hook checks -- is what a real abort triggers (ymt3_set_abort_recovery): in mode 1 that call
+ * returns the correct ids through the separate launches and ymt3_merged_fallbacks reports 1; in mode 0 its ids are all INT32_MIN and
+ * the call after it runs, correctly, on the separate launches.  YMT3_ERR_UNSUPPORTED if the handle does not run those kernels (fewer
+ * than 256 CUs, both switched off, or already fallen back). */
 int ymt3_debug_force_stage_abort(ymt3_handle h);
 
 /* Unit-test hooks: C = A(bf16 MxK) * W^T(bf16 NxK), f32 out; runs the encoder GEMM kernel. */

@@ -22,6 +22,11 @@ CASES = {
     "mc3_t64": (YMT3Config(segment_samples=8191, max_decode_len=32, n_channels=3), 2, 24),
 }
 LOGIT_STEPS = (0, 1, 23)
+# The whole decode length (round 3): configs[1] shapes, 2 segments x 1024 steps, EOS fill off.  Encoder output = that of "full_t256" (same
+# weights, same audio seed; the decode length does not enter the weights), so only ids, margins and logits at late positions are stored:
+# 127 | 382, 383, 384 (the self-attention's first full 384-key block and its second loop iteration) | 767 | 1023.
+LONG_CASE = ("full_t256_l1024", YMT3Config(max_decode_len=1024, eos_id=-1), 2, 1024)
+LONG_LOGIT_STEPS = (0, 127, 382, 383, 384, 767, 1023)
 
 
 def main():
@@ -45,6 +50,17 @@ def main():
             n_steps=np.int32(n_steps), seed_weights=np.int32(1234), seed_audio=np.int32(0),
         )
         print(name, "tokens", toks.shape, "distinct", len(set(toks.flatten().tolist())), "min margin", float(margin.min()))
+    name, cfg, B, n_steps = LONG_CASE
+    W = make_weights(cfg, seed=1234)
+    _, enc = O.encode(O.synthetic_audio(B, cfg, seed=0), W, cfg, bf16=True)
+    toks, logits = O.greedy_decode(enc, W, cfg, n_steps, bf16=True, return_logits=True)
+    top2 = logits.topk(2, -1).values
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), tokens=toks.numpy().astype(np.int32),
+                        margin=(top2[..., 0] - top2[..., 1]).numpy().astype(np.float32),
+                        logit_steps=np.array(LONG_LOGIT_STEPS, dtype=np.int32),
+                        logits=logits[:, :, list(LONG_LOGIT_STEPS), :].numpy().astype(np.float32),
+                        n_steps=np.int32(n_steps), seed_weights=np.int32(1234), seed_audio=np.int32(0), enc_from="full_t256")
+    print(name, "tokens", toks.shape, "distinct", len(set(toks.flatten().tolist())))
     # integer relative-position bucket tables (a5), both directions
     q = np.arange(512)[:, None]
     k = np.arange(512)[None, :]

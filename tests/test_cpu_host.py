@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_header_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ymt3_abi_version() == 2
+    assert lib.ymt3_abi_version() == 3
 
 
 def test_cconfig_matches_header_field_order():
@@ -115,6 +115,23 @@ def test_oracle_reproduces_golden_fixture(name, cfg, n):
     assert np.array_equal(f32_to_bf16_bits(enc), z["enc_bf16"])
     toks = O.greedy_decode(enc, W, cfg, n, True)
     assert np.array_equal(toks.numpy(), z["tokens"])
+
+
+def test_oracle_reproduces_the_full_length_golden_fixture():
+    """tests/golden/full_t256_l1024.npz: configs[1] shapes, 2 segments x 1024 steps, ids + margins + logits at late positions
+    (127 | 382, 383, 384 | 767 | 1023); its encoder output is the one stored in full_t256.npz."""
+    z = np.load(os.path.join(GOLD, "full_t256_l1024.npz"))
+    base = np.load(os.path.join(GOLD, str(z["enc_from"]) + ".npz"))
+    cfg = YMT3Config(max_decode_len=1024, eos_id=-1)
+    W = make_weights(cfg, seed=int(z["seed_weights"]))
+    enc = bf16_bits_to_f32(base["enc_bf16"]).view(2, cfg.n_frames, cfg.d_model)
+    toks, logits = O.greedy_decode(enc, W, cfg, int(z["n_steps"]), True, return_logits=True)
+    assert np.array_equal(toks.numpy(), z["tokens"])
+    steps = z["logit_steps"].tolist()
+    assert steps == [0, 127, 382, 383, 384, 767, 1023]
+    assert np.allclose(logits[:, :, steps, :].numpy(), z["logits"], atol=1e-5)
+    top2 = logits.topk(2, -1).values
+    assert np.allclose((top2[..., 0] - top2[..., 1]).numpy(), z["margin"], atol=1e-5)
 
 
 def test_perceiver_tf_oracle_shape_mixing_and_blob():

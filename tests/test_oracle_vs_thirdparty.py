@@ -172,6 +172,25 @@ def test_greedy_decode_matches_hf_generate_fp32(weights, hf):
     assert len(set(toks[0, 0].tolist())) > 8              # the stream is not a collapsed fixed point
 
 
+def test_decoder_matches_hf_at_every_position_of_a_1024_token_decode(weights):
+    """The oracle's cached step-by-step decode (self-attention cache append, unidirectional bias by distance with the past
+    offset: TP modeling_t5.py:264-279, 281-369) against HF's one-shot full-sequence decoder forward (causal mask, bias table for
+    all (query, key) pairs) at EVERY position of a 1024-token stream -- far past the bucket saturation (distance >= 128) and
+    the positions the HIP self-attention's long-sequence paths start at (383).  fp32 both sides: agreement to round-off."""
+    from transformers.modeling_outputs import BaseModelOutput
+    cfg = CFG.with_(max_decode_len=1024, eos_id=-1)
+    hf_long = _hf_model(weights, cfg.with_(eos_id=1))          # (eos only configures HF's generate; forward ignores it)
+    _, enc = O.encode(O.synthetic_audio(1, cfg), weights, cfg, bf16=False)
+    toks, logits = O.greedy_decode(enc, weights, cfg, 1024, bf16=False, return_logits=True)
+    dec_in = torch.cat([torch.full((1, 1), cfg.pad_id, dtype=torch.long), toks[:, 0, :-1].long()], 1)
+    with torch.no_grad():
+        ref = hf_long(encoder_outputs=BaseModelOutput(last_hidden_state=enc), decoder_input_ids=dec_in).logits     # (1, 1024, V)
+    err = (ref - logits[:, 0]).abs().amax(-1)[0]
+    assert err.max().item() < 1e-4, (err.max().item(), int(err.argmax()))
+    assert torch.equal(ref.argmax(-1)[0], toks[0, 0].long())
+    assert len(set(toks[0, 0, 512:].tolist())) > 30          # still a varied stream late in the decode
+
+
 def test_eos_fill_matches_hf(weights, hf):
     # force an early EOS by making the EOS row of the head dominant from step 3 on is hard with random
     # weights; instead check the fill rule directly on a crafted logits sequence via the oracle loop.

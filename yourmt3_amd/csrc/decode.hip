@@ -1123,8 +1123,8 @@ int launch_dg_mid(const DecGemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-// many rows: the mid-size tile kernel from DEC_GEMM_MID_ROWS rows on (YMT3_DEC_GEMM_MID_ROWS overrides the threshold, 0 = never: A/B timing)
-constexpr int DEC_GEMM_MID_ROWS = 512;
+// many rows: the mid-size tile kernel from DEC_GEMM_MID_ROWS rows on (kernels.h; a handle created under YMT3_DEC_GEMM_MID_ROWS=n passes its own
+// threshold in DecGemmArgs::mid_rows, 0 = never: A/B timing, and the late-position parity test of the many-row kernels at a few rows)
 static int launch_dec_gemm_mid(int mode, const DecGemmArgs& a, hipStream_t stream) {
     if (a.N % 64 || a.part) return -1;
     switch (mode) {
@@ -1144,7 +1144,7 @@ static int launch_dec_gemm_mid(int mode, const DecGemmArgs& a, hipStream_t strea
 int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
     if (a.N % 16) return -1;
-    static const int mid_rows = getenv("YMT3_DEC_GEMM_MID_ROWS") ? atoi(getenv("YMT3_DEC_GEMM_MID_ROWS")) : DEC_GEMM_MID_ROWS;
+    const int mid_rows = a.mid_rows >= 0 ? a.mid_rows : DEC_GEMM_MID_ROWS;
     if (mid_rows > 0 && a.R >= mid_rows && a.N % 64 == 0 && !a.part && !a.pend_y && (a.K == 512 || (a.K == 2048 && mode == DG_RESID)))
         return launch_dec_gemm_mid(mode, a, stream);
     if (mode == DG_RESID) {
@@ -1170,7 +1170,7 @@ int launch_dec_gemm(int mode, const DecGemmArgs& a, hipStream_t stream) {
 
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream) {
     if (a.R <= 0) return 0;
-    const bool many = a.R * a.H > 2048;
+    const bool many = a.force_many || a.R * a.H > 2048;
     if (a.chain_sync && (self_attn || !a.wq)) return -1;                              // only the fused cross-attention zeroes the chain counters
     if ((a.wo || a.ipart) && (many || a.H != 8 || (a.wo && !a.opart) || (a.ipart && !a.wq))) return -1;   // folded O-projection: 8 heads, 8-wave kernels
     if (a.row0 < 0 || a.row0 > 0xffff || a.rows_per_kv < 1 || a.rows_per_kv > 0xff || a.H < 1 || a.H > 0xff || a.slab_keys < 1 || a.slab_keys > 0xfffff ||

@@ -116,7 +116,9 @@ struct DecGemmArgs {
     // the residual row is x_f32 + (y[2r] + y[2r+1]) and the workgroups of column tile 0 store it to h_out (QKV mode)
     const float* pend_y;
     float* h_out;
+    int mid_rows;               // row count from which the mid-size tile kernel is taken; < 0: DEC_GEMM_MID_ROWS; 0: never (handle-level: YMT3_DEC_GEMM_MID_ROWS at create)
 };
+constexpr int DEC_GEMM_MID_ROWS = 512;
 // The four skinny GEMMs between a layer's cross-attention and the next layer's self-attention as one launch (dec_chain.hip):
 // cross O-projection -> FFN-in -> FFN-out -> next QKV projection (or lm_head); dense FFN, d_model = 512, d_ff = 2048, R <= 64.
 struct ChainArgs {
@@ -181,6 +183,7 @@ struct DecAttnArgs {
     float* opart;               // [R][H][512]
     const float* ipart;         // [R][H][512]
     unsigned* chain_sync;       // fused cross-attention, or null: the arrival counters of the GEMM chain launched next (dec_chain.hip), zeroed here
+    int force_many;             // test knob (YMT3_SELF_ATTN_2WAVE=1 at create): take the 2-waves-per-(row, head) form whatever the row count
 };
 int launch_dec_attention(bool self_attn, const DecAttnArgs& a, hipStream_t stream);
 // one layer's self-attention (folded O-projection) and fused cross-attention as one launch (decode.hip: dec_attn_pair_kernel);

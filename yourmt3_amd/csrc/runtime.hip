@@ -49,6 +49,7 @@ struct Tensor {
 struct StepGraph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    bool merged = false;            // the captured steps contain merged kernels (GEMM chain / attention pair): their abort word must be looked at
 };
 
 struct ymt3_ctx {
@@ -107,8 +108,15 @@ struct ymt3_ctx {
     bool gemm_chain = true;                 // cross O -> FFN-in -> FFN-out -> next QKV / lm_head as one launch (dec_chain.hip; YMT3_NO_GEMM_CHAIN=1: four launches)
     unsigned* chain_sync = nullptr;         // [CHAIN_SYNC_WORDS] device: the chain kernel's arrival counters + sticky abort word
     unsigned* chain_host_abort = nullptr;   // pinned: set by the chain kernel together with the abort word; checked at every call
-    bool chain_used = false;                // the last captured / launched step contains chain launches
+    bool step_merged = false;               // set by launch_step: the step it just captured / launched contains merged kernels
     bool forced_abort = false;              // ymt3_debug_force_stage_abort: raise the host word after the next decode call, as a kernel would during it
+    // What happens when a merged kernel gives up waiting (ymt3_set_abort_recovery): 1 (default) = every decode call that ran merged kernels ends
+    // by waiting for its stream and looking at the abort word; an abort re-runs the call through the separate launches (same bits) and the
+    // handle stays on them.  0 = fully asynchronous calls: an aborted call's ids are INT32_MIN and the NEXT call on the handle switches over.
+    int abort_recovery = 1;
+    int fallback_count = 0;                 // how often this handle fell back from the merged kernels to the separate launches (0 or 1)
+    int mid_rows = -1;                      // YMT3_DEC_GEMM_MID_ROWS at create: decode GEMMs take mid-size tiles from this many rows on (-1: DEC_GEMM_MID_ROWS, 0: never)
+    bool force_2wave = false;               // YMT3_SELF_ATTN_2WAVE=1 at create (test knob): the many-row 2-wave self-attention at any row count
     bool attn_pair = true;                  // a layer's self- and cross-attention as one launch (decode.hip: dec_attn_pair_kernel; YMT3_NO_ATTN_PAIR=1: two)
     unsigned* pair_rows = nullptr;          // [maxR <= 64][2] counter lines of that kernel (zero between launches)
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
@@ -344,13 +352,16 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->row_out, R * 8)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->ssq, (size_t)SSQ_TILES * R * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->opart, R * k.n_heads * d * 4)) return YMT3_ERR_HIP;
-    {   // the GEMM chain needs every workgroup of its grid resident at once: one 143 KB-LDS workgroup per CU, 256 CUs
+    {   // The merged decode kernels (GEMM chain: 256 workgroups of 143 KB LDS; attention pair: 512 of 72 KB) wait for each other inside one
+        // launch, so every workgroup of their grids must be resident at once: a kernel is enabled only if the switch allows it AND the
+        // runtime's occupancy answer x CUs covers its grid.  YMT3_TEST_CHAIN_UNFIT / YMT3_TEST_PAIR_UNFIT = 1 force "does not fit" for
+        // one kernel (tests: a partition on which only one of the two fits must take the separate launches for the other).
+        auto env1 = [](const char* n) { const char* v = getenv(n); return v && v[0] == '1'; };
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-        if (init_chain_kernels()) c->gemm_chain = c->attn_pair = false;
-        // every workgroup of a merged kernel's grid must be resident at once: ask the runtime what fits (256 CUs on an MI355X)
-        if (c->gemm_chain && !dec_chain_fits(prop.multiProcessorCount)) c->gemm_chain = false;
-        if (c->attn_pair && !dec_attention_pair_fits(prop.multiProcessorCount)) c->attn_pair = false;
+        const bool init_ok = init_chain_kernels() == 0;
+        c->gemm_chain = !env1("YMT3_NO_GEMM_CHAIN") && init_ok && !env1("YMT3_TEST_CHAIN_UNFIT") && dec_chain_fits(prop.multiProcessorCount);
+        c->attn_pair = !env1("YMT3_NO_ATTN_PAIR") && init_ok && !env1("YMT3_TEST_PAIR_UNFIT") && dec_attention_pair_fits(prop.multiProcessorCount);
         if (c->gemm_chain || c->attn_pair) {
             if (dev_alloc(c, (void**)&c->chain_sync, CHAIN_SYNC_WORDS * sizeof(unsigned))) return YMT3_ERR_HIP;
             HIP_TRY(hipMemset(c->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
@@ -387,10 +398,11 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     c->moe_fold_combine = !(mcl && mcl[0] == '1');
     const char* nfo = getenv("YMT3_NO_FOLD_O");          // A/B: keep the separate self-attention O-projection launch
     c->fold_o = !(nfo && nfo[0] == '1');
-    const char* ngc = getenv("YMT3_NO_GEMM_CHAIN");      // A/B: the skinny GEMMs between cross-attention and the next self-attention as four launches
-    c->gemm_chain = !(ngc && ngc[0] == '1');
-    const char* nap = getenv("YMT3_NO_ATTN_PAIR");       // A/B: self-attention and cross-attention as two launches
-    c->attn_pair = !(nap && nap[0] == '1');
+    // (YMT3_NO_GEMM_CHAIN / YMT3_NO_ATTN_PAIR = 1 -- the skinny GEMMs as four launches, the two attentions as two -- are read above, with the fit decisions)
+    if (const char* mr = getenv("YMT3_DEC_GEMM_MID_ROWS")) c->mid_rows = atoi(mr) < 0 ? -1 : atoi(mr);
+    const char* f2 = getenv("YMT3_SELF_ATTN_2WAVE");
+    c->force_2wave = f2 && f2[0] == '1';
+    if (const char* ar = getenv("YMT3_ABORT_RECOVERY")) c->abort_recovery = ar[0] == '0' ? 0 : 1;
     const char* nc = getenv("YMT3_CHAINS");
     if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
     const char* ct = getenv("YMT3_CHAIN_THREADS");
@@ -436,13 +448,37 @@ extern "C" int ymt3_create(const ymt3_config* cfg, const void* blob, size_t nbyt
 }
 
 // ------------------------------------------------------------------------------------------------
+// A merged decode kernel gave up waiting (its sticky abort word is raised): leave the merged kernels for good.  The caller has made sure
+// nothing of this handle is still running.  Counters, abort words and the cached step graphs (they hold merged launches) are reset; the
+// separate launches compute the same bits, so the handle goes on working.
+static int merged_fallback(ymt3_ctx* h) {
+    h->gemm_chain = h->attn_pair = false;
+    ++h->fallback_count;
+    h->forced_abort = false;
+    for (auto& kv : h->step_graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    h->step_graphs.clear();
+    if (h->chain_sync) HIP_TRY(hipMemset(h->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
+    if (h->pair_rows) HIP_TRY(hipMemset(h->pair_rows, 0, (size_t)64 * 2 * CHAIN_LINE * sizeof(unsigned)));
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->chain_host_abort) *h->chain_host_abort = 0u;
+    return YMT3_OK;
+}
+
 static int check_call(ymt3_handle h, int B) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");
     if (B < 0 || B > h->maxB) FAIL(YMT3_ERR_ARG, "B=%d outside [0, max_batch=%d]", B, h->maxB);
     HIP_TRY(hipSetDevice(h->device));
-    if (h->chain_host_abort && *static_cast<volatile unsigned*>(h->chain_host_abort))
-        FAIL(YMT3_ERR_HIP, "a decode GEMM-chain launch gave up waiting for one of its stages (> 1 s; were all 256 CUs available to it?): the token ids "
-                           "of that call were overwritten with INT32_MIN and this handle refuses further work (YMT3_NO_GEMM_CHAIN=1 avoids the kernel)");
+    if (h->chain_host_abort && *static_cast<volatile unsigned*>(h->chain_host_abort)) {
+        // an earlier call's merged kernel gave up (> 1 s without its co-resident workgroups: were all CUs available to it?) and nobody has
+        // dealt with it yet (ymt3_set_abort_recovery(h, 0), or a measurement call): that call's ids are INT32_MIN; this and every later
+        // call run the separate launches
+        HIP_TRY(hipDeviceSynchronize());
+        int rc = merged_fallback(h);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -599,7 +635,7 @@ extern "C" int ymt3_encode(ymt3_handle h, const float* mel_dev, int B, void* enc
 
 // one decoder step of rows [row0, row0 + R) = 8 kernels per layer + lm_head + argmax, all reading the
 // position from the chain's DecodeShared
-static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shared, hipStream_t s) {
+static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shared, hipStream_t s, bool solo = true) {
     const ymt3_config& k = h->cfg;
     const int d = k.d_model, inner = h->inner, H = k.n_heads, L = k.max_decode_len;
     const size_t layer_cache = (size_t)h->maxR * H * L * 64;
@@ -642,24 +678,36 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     // MoE with the combine folded away: after an MoE FFN the residual stream is hcur + (y[2r] + y[2r+1]) until the next norm GEMM
     // (the next layer's QKV projection, or lm_head) has formed it; that QKV kernel stores it to the other buffer, which the rest of
     // its layer then uses.  Needs the 16-row decode GEMMs (below the mid-size tile threshold).
-    const bool fold_combine = k.dec_ffn == YMT3_FFN_MOE && h->moe_fold_combine && R < 512;
+    const bool fold_combine = k.dec_ffn == YMT3_FFN_MOE && h->moe_fold_combine && R < (h->mid_rows > 0 ? h->mid_rows : (h->mid_rows < 0 ? DEC_GEMM_MID_ROWS : 1 << 30));
     float* hcur = h->h_dec;
     const float* pend = nullptr;
+    // all channels of a segment share its cross-attention K/V: one workgroup per (segment, head) serves them together (mc_cross_attn.hip)
+    const bool mc = h->fuse_q && k.n_channels >= 2 && k.n_channels <= 16 && (h->T == 128 || h->T == 256 || h->T == 512) &&
+                    row0 % k.n_channels == 0 && R % k.n_channels == 0;
+    // fold_o: the self-attention kernel leaves per-head O-projection partials; the fused cross-attention and the cross
+    // O-projection's residual read sum them (one launch less per layer, same bits).  Needs the 8-wave attention kernels
+    // and the per-row fused cross-attention
+    // and pays only while the per-(row, head) pull of wo (64 KB each) stays small against the launch it removes: +0.3 % at 64 rows,
+    // -1.4 % at 128, -3.5 % at 256 (profiles/r02_b256_fold_fuseq_variants.txt); same bits either way
+    const bool fold = h->fold_o && h->fuse_q && !mc && !h->force_2wave && H == 8 && d == 512 && R <= 96;
+    // The merged kernels' regime: one channel, up to 64 rows, and this step the only decode stream of the handle (`solo`: with YMT3_CHAINS > 1
+    // other row ranges replay on other streams, and the merged kernels need every CU for their own workgroups while they run).
+    const bool merged_regime = fold && solo && k.n_channels == 1 && R <= 64 && row0 == 0;
     // GEMM chain (dec_chain.hip): after a layer's cross-attention, ONE launch does the cross O-projection, the FFN and the NEXT
-    // layer's QKV projection (or lm_head) -- decided per step shape, same bits as the four launches.  One chain per handle at a time
-    // (its arrival counters are per handle), so not with YMT3_CHAINS > 1 row ranges.
-    const bool chain = h->gemm_chain && h->chain_sync && h->fold_o && h->fuse_q && k.dec_ffn != YMT3_FFN_MOE && k.n_channels == 1 && H == 8 &&
-                       d == 512 && inner == 512 && k.d_ff == 2048 && R <= 64 && row0 == 0 && k.vocab % 32 == 0 && k.vocab / 32 >= 32 && k.vocab / 32 <= 64;
+    // layer's QKV projection (or lm_head) -- decided per step shape, same bits as the four launches.
+    const bool chain = h->gemm_chain && h->chain_sync && merged_regime && k.dec_ffn != YMT3_FFN_MOE && inner == 512 && k.d_ff == 2048 &&
+                       k.vocab % 32 == 0 && k.vocab / 32 >= 32 && k.vocab / 32 <= 64;
     // attention pair (decode.hip: dec_attn_pair_kernel): a layer's two attention kernels as one launch wherever the folded
     // O-projection and the fused query projection apply to one channel of up to 64 rows (dense or MoE FFN alike)
-    const bool pair_ok = h->attn_pair && h->pair_rows && h->fold_o && h->fuse_q && k.n_channels == 1 && H == 8 && d == 512 && R <= 64 && row0 == 0;
-    h->chain_used = chain || pair_ok;
+    const bool pair_ok = h->attn_pair && h->pair_rows && merged_regime;
+    h->step_merged = chain || pair_ok;
     bool qkv_done = false, lm_done = false;         // the previous layer's chain launch already did this layer's QKV / the lm_head
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const LayerW& W = LW[l];
         DecGemmArgs a{};
         a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
         a.row_pos = h->slot_mode ? h->row_pos : nullptr;
+        a.mid_rows = h->mid_rows;
         // self-attention block
         a.x_f32 = hcur; a.gain = W.ln1; a.W = W.wqkv; a.N = 3 * inner; a.K = d; a.out_bf16 = h->dq;
         if (pend) {                                  // the previous layer's expert outputs are still to be added: x -> the other buffer
@@ -676,15 +724,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         DecAttnArgs t{};
         t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
         t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
-        t.row_pos = a.row_pos;
-        const bool mc = h->fuse_q && k.n_channels >= 2 && k.n_channels <= 16 && (h->T == 128 || h->T == 256 || h->T == 512) &&
-                        row0 % k.n_channels == 0 && R % k.n_channels == 0;
-        // fold_o: the self-attention kernel leaves per-head O-projection partials; the fused cross-attention and the cross
-        // O-projection's residual read sum them (one launch less per layer, same bits).  Needs the 8-wave attention kernels
-        // and the per-row fused cross-attention
-        // and pays only while the per-(row, head) pull of wo (64 KB each) stays small against the launch it removes: +0.3 % at 64 rows,
-        // -1.4 % at 128, -3.5 % at 256 (profiles/r02_b256_fold_fuseq_variants.txt); same bits either way
-        const bool fold = h->fold_o && h->fuse_q && !mc && H == 8 && d == 512 && R <= 96;
+        t.row_pos = a.row_pos; t.force_many = h->force_2wave ? 1 : 0;
         if (fold) { t.wo = W.wo; t.opart = h->opart; }
         const bool pair = pair_ok && fold;
         DecAttnArgs ts = t;                          // the self-attention half
@@ -769,6 +809,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     }
     DecGemmArgs a{};
     a.row0 = row0; a.R = R; a.eps = k.ln_eps; a.H = H; a.L = L; a.shared = shared; a.ssq = h->ssq; a.ssq_stride = h->maxR;
+    a.mid_rows = h->mid_rows;
     GET(h, "dec.ln_f", 0u, &f, (size_t)d);
     a.x_f32 = hcur; a.gain = f; a.W = lm_head; a.N = k.vocab; a.K = d; a.out_f32 = h->logits;
     a.pend_y = pend;                                 // the last layer's expert outputs, if their combine was folded away
@@ -787,11 +828,20 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     return YMT3_OK;
 }
 
+static int decode_run(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int32_t* tokens, const int32_t* forced,
+                      float* logits_out, hipStream_t s, int prof_stride, int step0);
+
 static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int32_t* tokens, const int32_t* forced,
                        float* logits_out, hipStream_t s, int prof_stride = 0) {
-    const ymt3_config& k = h->cfg;
     const int step0 = h->prof_step0;          // one shot (debug hook): consumed by this call whatever its outcome
     h->prof_step0 = 0;
+    return decode_run(h, enc, B, n_steps, tokens, forced, logits_out, s, prof_stride, step0);
+}
+
+static int decode_run(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int32_t* tokens, const int32_t* forced,
+                      float* logits_out, hipStream_t s, int prof_stride, int step0) {
+    const ymt3_config& k = h->cfg;
+    bool merged = false;                      // some step of this call ran merged kernels
     if (n_steps <= 0 || step0 + n_steps > k.max_decode_len) FAIL(YMT3_ERR_ARG, "n_steps=%d outside [1, max_decode_len=%d]", n_steps, k.max_decode_len - step0);
     const int d = k.d_model, R = B * k.n_channels;
     // a6: cross-attention K/V of every decoder layer in one GEMM, stored as per-(segment, head) slabs
@@ -833,6 +883,7 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
             int rc = launch_step(h, B, 0, R, h->shared, s);
             h->prof_on = false;
             if (rc) return rc;
+            merged = merged || h->step_merged;
         }
         if (h->prof_span_open) {            // a span the loop never closed: drop it (its end event was never recorded)
             (void)hipEventRecord(h->prof_ev[h->prof_span_idx], s);
@@ -845,13 +896,15 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
             StepGraph& sg = h->step_graphs[((long)B * 16 + n_chains) * 16 + c];
             if (!sg.exec) {
                 HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-                int rc = launch_step(h, B, row0[c], row0[c + 1] - row0[c], h->shared + c, h->cap_stream);
+                int rc = launch_step(h, B, row0[c], row0[c + 1] - row0[c], h->shared + c, h->cap_stream, n_chains == 1);
                 hipError_t e = hipStreamEndCapture(h->cap_stream, &sg.graph);
                 if (rc) return rc;
                 if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
                 HIP_TRY(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+                sg.merged = h->step_merged;
             }
             exec[c] = sg.exec;
+            merged = merged || sg.merged;
         }
         if (n_chains == 1 && h->early_stop_interval > 0 && k.eos_id >= 0 && !forced) {
             // opt-in (ymt3_set_early_stop): every `interval` steps the host reads how many rows are still decoding and
@@ -885,7 +938,9 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
                     if (rc) return rc;
                     if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
                     HIP_TRY(hipGraphInstantiate(&mg.exec, mg.graph, nullptr, nullptr, 0));
+                    mg.merged = h->step_merged;
                 }
+                merged = merged || mg.merged;
                 for (; t + G <= n_steps; t += G) HIP_TRY(hipGraphLaunch(mg.exec, s));
             }
             for (; t < n_steps; ++t) HIP_TRY(hipGraphLaunch(exec[0], s));
@@ -919,9 +974,26 @@ static int decode_impl(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int
             }
         }
     }
-    // a GEMM-chain launch that gave up on a stage (dec_chain.hip) must not leave plausible ids behind
-    if (h->chain_used) LAUNCH(launch_chain_poison(h->chain_sync, tokens, (long long)R * n_steps, s));
-    if (h->forced_abort && h->chain_host_abort) { *h->chain_host_abort = 1u; h->forced_abort = false; }
+    if (merged) {
+        // a merged launch that gave up on a stage (dec_chain.hip, dec_attn_pair_kernel) must not leave plausible ids behind
+        LAUNCH(launch_chain_poison(h->chain_sync, tokens, (long long)R * n_steps, s));
+        HIP_TRY(hipGetLastError());
+        if (h->abort_recovery && prof_stride == 0) {
+            // Recovery (ymt3_set_abort_recovery, default on): wait for the call's own work and look at the abort word.  Raised -- a
+            // stage waited > 1 s for workgroups that were not resident: another kernel held CUs -- the call is run again through the
+            // separate launches (fresh launches in this process, the same arithmetic bit for bit) and the handle stays on them.
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h->forced_abort && h->chain_host_abort) *h->chain_host_abort = 1u;      // debug hook: as a kernel would have during the call
+            if (h->chain_host_abort && *static_cast<volatile unsigned*>(h->chain_host_abort)) {
+                int rc = merged_fallback(h);
+                if (rc) return rc;
+                return decode_run(h, enc, B, n_steps, tokens, forced, logits_out, s, prof_stride, step0);
+            }
+        } else if (h->forced_abort && h->chain_host_abort) {
+            *h->chain_host_abort = 1u;            // asynchronous mode: the next call on the handle finds the word (check_call)
+            h->forced_abort = false;
+        }
+    }
     HIP_TRY(hipGetLastError());
     return YMT3_OK;
 }
@@ -1001,6 +1073,7 @@ extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int
             if (rcs) return rcs;
             if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
             HIP_TRY(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+            sg.merged = h->step_merged;
         }
         exec = sg.exec;
     }
@@ -1036,8 +1109,13 @@ extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int
         }
         HIP_TRY(hipMemcpyAsync(h->host_rows, h->finished, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (h->chain_host_abort && *static_cast<volatile unsigned*>(h->chain_host_abort))
-            FAIL(YMT3_ERR_HIP, "a decode GEMM-chain launch gave up waiting for one of its stages; the ids of this call are invalid");
+        if (h->forced_abort && h->chain_host_abort) *h->chain_host_abort = 1u;          // debug hook: as a kernel would have during the round
+        if (h->chain_host_abort && *static_cast<volatile unsigned*>(h->chain_host_abort)) {
+            // a merged kernel gave up (the stream is idle here): start the queue again on the separate launches -- same ids
+            rc = merged_fallback(h);
+            if (rc) return rc;
+            return ymt3_transcribe_stream(h, audio_dev, n_segments, n_steps, tokens_dev, slots, interval, stream);
+        }
         free_slots.clear();
         for (int slot = 0; slot < slots; ++slot) {
             if (slot_seg[(size_t)slot] < 0) continue;
@@ -1136,7 +1214,7 @@ extern "C" int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* sta
 extern "C" int ymt3_debug_force_stage_abort(ymt3_handle h) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");
     if (!h->debug_hooks) FAIL(YMT3_ERR_UNSUPPORTED, "debug hooks are accepted only by a handle created with YMT3_DEBUG_HOOKS=1 in the environment");
-    if (!h->chain_sync || !h->chain_host_abort) FAIL(YMT3_ERR_UNSUPPORTED, "this handle does not run the merged decode kernels");
+    if (!h->chain_sync || !h->chain_host_abort || !(h->gemm_chain || h->attn_pair)) FAIL(YMT3_ERR_UNSUPPORTED, "this handle does not run the merged decode kernels");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     const unsigned one = 1u;
@@ -1265,6 +1343,15 @@ extern "C" int ymt3_ingest(ymt3_handle h, const void* pcm_dev, int pcm_format, i
 }
 
 extern "C" int ymt3_last_decode_steps(ymt3_handle h) { return h ? h->last_steps : 0; }
+
+extern "C" int ymt3_merged_fallbacks(ymt3_handle h) { return h ? h->fallback_count : 0; }
+
+extern "C" int ymt3_set_abort_recovery(ymt3_handle h, int mode) {
+    if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (mode != 0 && mode != 1) FAIL(YMT3_ERR_ARG, "mode must be 0 (asynchronous, lazy) or 1 (verify every merged decode call)");
+    h->abort_recovery = mode;
+    return YMT3_OK;
+}
 
 extern "C" int ymt3_set_early_stop(ymt3_handle h, int interval) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");

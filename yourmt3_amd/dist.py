@@ -85,11 +85,9 @@ def init_distributed(n_gpus: int = 1) -> Tuple[int, int, int]:
         backend = os.environ.get("YMT3_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             n_dev = max(1, torch.cuda.device_count())
-            if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > n_dev:
-                # several ranks rehearsing on one GPU: the merged decode kernels (csrc/dec_chain.hip, dec_attn_pair_kernel) need every CU for THEIR workgroups
-                # while it runs, and two of them from different processes can starve each other until both give up
-                os.environ.setdefault("YMT3_NO_GEMM_CHAIN", "1")
-                os.environ.setdefault("YMT3_NO_ATTN_PAIR", "1")
+            # (Several ranks rehearsing on ONE GPU can starve each other's merged decode kernels, which need every CU for their own workgroups
+            # while they run: a stage then gives up after 1 s, the call is re-run through the separate launches -- same ids -- and the
+            # handle stays on them: include/ymt3.h, ymt3_set_abort_recovery.  Nothing to arrange here.)
             local_rank %= n_dev
         kw = {}
         if backend == "nccl":

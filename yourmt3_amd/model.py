@@ -73,6 +73,16 @@ class YourMT3:
         """Decoder steps the last decode / inference call launched (fewer than asked for after an early stop)."""
         return int(self._lib.ymt3_last_decode_steps(self._handle))
 
+    @property
+    def merged_fallbacks(self) -> int:
+        """How often this handle left the merged decode kernels for the separate launches after one gave up waiting (0 or 1)."""
+        return int(self._lib.ymt3_merged_fallbacks(self._handle))
+
+    def set_abort_recovery(self, mode: int) -> None:
+        """1 (default): decode calls verify at their end that no merged kernel gave up and re-run through the separate launches if
+        one did; 0: fully asynchronous calls, an aborted call's ids are INT32_MIN and the next call switches over (include/ymt3.h)."""
+        _lib.check(self._lib.ymt3_set_abort_recovery(self._handle, int(mode)))
+
     def set_early_stop(self, interval: int) -> None:
         """Check every `interval` steps whether all rows have emitted EOS and stop decoding once they have (0 = off)."""
         _lib.check(self._lib.ymt3_set_early_stop(self._handle, int(interval)))
