@@ -188,7 +188,7 @@ def cpu_baseline():
 def run(args):
     import torch
     from yourmt3_amd.config import baseline_config
-    from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens
+    from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens, gather_floats
     from yourmt3_amd.model import YourMT3
 
     rank, world, local_rank = init_distributed(args.gpus)
@@ -206,8 +206,14 @@ def run(args):
     assert audio.shape[0] == B
 
     def step():
+        """one pass of the hot path + the all-gather of the ids; returns (ids, seconds of this rank's own work, seconds in the all-gather)"""
+        s0 = time.perf_counter()
         toks = model.inference(audio, max_token_length=L)
-        return all_gather_tokens(toks, world)
+        torch.cuda.synchronize(dev)          # (the decode call has waited for its own work already: include/ymt3.h, ymt3_set_abort_recovery)
+        s1 = time.perf_counter()
+        gathered = all_gather_tokens(toks, world)
+        torch.cuda.synchronize(dev)
+        return gathered, s1 - s0, time.perf_counter() - s1
 
     def fence():
         if world > 1:
@@ -217,19 +223,24 @@ def run(args):
     for _ in range(args.warmup):
         step()
     fence()
-    lat = []
+    lat, own, coll = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        s0 = time.perf_counter()
-        out = step()
-        torch.cuda.synchronize(dev)
-        lat.append(time.perf_counter() - s0)
+        out, t_own, t_coll = step()
+        lat.append(t_own + t_coll)
+        own.append(t_own)
+        coll.append(t_coll)
+    t_rank = time.perf_counter() - t0            # this rank's K steps, before it waits for the others
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    # every rank's own times travel to rank 0's line: ms per step, ms of its own work (front-end .. ids), ms inside the all-gather
+    # (= waiting for the slowest rank + the transfer itself)
+    per_rank = gather_floats([1e3 * t_rank / args.steps, 1e3 * statistics.mean(own), 1e3 * statistics.mean(coll),
+                              1e3 * min(coll), float(model.merged_fallbacks)], world, dev)
     assert out.shape == (B * world, cfg.n_channels, L)
 
     audio_seconds = args.steps * world * B * cfg.segment_seconds
@@ -244,6 +255,16 @@ def run(args):
         "dtype": "bf16", "data": "synthetic",
         "p50_segment_latency_ms": 1e3 * statistics.median(lat) / B,
         "p50_batch_latency_ms": 1e3 * statistics.median(lat),
+        "per_rank": {
+            "ms_per_step": [round(r[0], 3) for r in per_rank],
+            "ms_own_work": [round(r[1], 3) for r in per_rank],
+            "ms_all_gather_mean": [round(r[2], 3) for r in per_rank],
+            "ms_all_gather_min": [round(r[3], 3) for r in per_rank],
+            "merged_kernel_fallbacks": [int(r[4]) for r in per_rank],
+            "note": "one entry per rank: its own K steps / K (before the closing barrier); its own work per step (audio in HBM -> ids, "
+                    "synchronised); mean and minimum time per step inside the RCCL all-gather of the ids (waiting for the slowest rank + "
+                    "the transfer: the minimum over steps is close to the transfer alone); whether the rank left the merged decode kernels",
+        },
         "config": {
             "workload": "BASELINE configs[1]: MT3 base (T5-small dims, 6+6 layers, d512, 8x64 heads, d_ff 2048, vocab 1536), "
                         f"{cfg.segment_seconds:.3f} s / 16 kHz / 128-mel segments ({cfg.n_frames} encoder frames), greedy decode forced to "

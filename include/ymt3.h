@@ -167,6 +167,13 @@ int ymt3_debug_decode_start(ymt3_handle h, int step0);
  * than 256 CUs, both switched off, or already fallen back). */
 int ymt3_debug_force_stage_abort(ymt3_handle h);
 
+/* Debug hook, gated like the ones above (MoE decoder FFN only): from now on every lock-step decode call records the router's choices,
+ * trace_dev[step][layer][row][2] int32 (the two chosen experts, best first; steps >= n_steps or rows >= n_rows are not recorded); NULL
+ * stops recording.  A routing choice is discrete: at a near-tie of the 2nd / 3rd router logit the HIP path may legitimately pick another
+ * expert than the CPU oracle.  With the trace a test feeds the HIP path's choices to the oracle, checks each was within the numerical
+ * noise of the oracle's own top two, and compares logits / ids at EVERY step instead of excluding the near-tie steps. */
+int ymt3_debug_moe_trace(ymt3_handle h, int32_t* trace_dev, int n_steps, int n_rows);
+
 /* Unit-test hooks: C = A(bf16 MxK) * W^T(bf16 NxK), f32 out; runs the encoder GEMM kernel. */
 int ymt3_test_gemm(ymt3_handle h, const void* a_dev, const void* w_dev, float* c_dev, int M, int N, int K, void* stream);
 

@@ -53,7 +53,7 @@ def perceiver_tf_latents(mel: Tensor, W: Dict[str, Tensor], cfg, bf16: bool) -> 
     B, T, F = mel.shape
     K, D, eps = cfg.n_latents, cfg.ptf_d, cfg.ln_eps
     xn = spectral_features(mel, W, cfg, bf16).reshape(B * T, F, D)
-    z = W["ptf.latents"][None, None].expand(B, T, K, D).float().contiguous()
+    z = W["ptf.latents"][None, None].expand(B, T, K, D).to(mel.dtype).contiguous()
     H = D // 64
     bias_off = encoder_bias_by_offset(W["ptf.relbias"], T, cfg)                # (H, 2T-1)
     idx = (torch.arange(T)[None, :] - torch.arange(T)[:, None]) + (T - 1)        # key - query + T-1
@@ -81,6 +81,11 @@ def perceiver_tf_latents(mel: Tensor, W: Dict[str, Tensor], cfg, bf16: bool) -> 
         zt = _ffn(zt, W, p + "t.", eps, bf16)
         z = zt.reshape(B, K, T, D).transpose(1, 2).contiguous()
     return z
+
+
+def in_double(W: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """The weights cast to float64: with a float64 `mel` the encoder below accumulates every sum in double, rounding points unchanged."""
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in W.items()}
 
 
 def encoder_perceiver_tf(mel: Tensor, W: Dict[str, Tensor], cfg, bf16: bool) -> Tensor:

@@ -129,13 +129,15 @@ def decoder_bias_by_distance(relbias: Tensor, L: int, cfg) -> Tensor:
 # building blocks
 # --------------------------------------------------------------------------------------------
 def _r(x: Tensor, on: bool) -> Tensor:
-    """bf16 round-to-nearest-even rounding point (identity in the fp32 restatement)."""
-    return x.to(torch.bfloat16).to(torch.float32) if on else x
+    """bf16 round-to-nearest-even rounding point (identity in the fp32 restatement).  The result keeps x's dtype: run on float64
+    tensors (weights and inputs cast to double) the whole oracle accumulates in double with the SAME rounding points -- a second
+    evaluation order, used by tests to measure how far two correct bf16 implementations of one model legitimately differ."""
+    return x.to(torch.bfloat16).to(x.dtype if x.dtype == torch.float64 else torch.float32) if on else x
 
 
 def rmsnorm(x: Tensor, gain: Tensor, eps: float) -> Tensor:
     """TP: modeling_t5.py:50-72 -- no mean subtraction, fp32 accumulation."""
-    var = x.float().pow(2).mean(-1, keepdim=True)
+    var = (x if x.dtype == torch.float64 else x.float()).pow(2).mean(-1, keepdim=True)
     return x * torch.rsqrt(var + eps) * gain
 
 
@@ -241,6 +243,14 @@ FP8_MAX = 448.0
 # A row whose gap is below the numerical noise can legitimately route to a different expert on the GPU (a discrete
 # change worth ~0.2 in the logits), so parity tests exclude such (row, step) pairs -- the same policy as argmax margins.
 MOE_ROUTER_MARGINS = None
+# When an iterator, moe_ffn takes its top-k from it instead of from its own router logits: one (rows, k) integer tensor per call (the
+# HIP path's recorded choices, ymt3_debug_moe_trace), and appends to MOE_FORCED_DEFICIT, per call, the (rows,) tensor
+#   max(0, oracle's k-th largest logit - the smallest oracle logit among the forced experts):
+# 0 where the forced set IS the oracle's top-k, otherwise how far below the oracle's cut the worst forced expert lies -- a legitimate
+# near-tie choice has a deficit within the numerical noise of the router logits.
+MOE_FORCED_SEL = None
+MOE_FORCED_DEFICIT = None
+MOE_CHOSEN = None          # when a list, moe_ffn appends the (rows, k) experts it used (its own top-k, or the forced ones)
 
 
 def quant_rows_fp8(x: Tensor):
@@ -265,6 +275,15 @@ def moe_ffn(xn: Tensor, W: Dict[str, Tensor], p: str, cfg, bf16: bool) -> Tensor
     logits = xn @ W[p + "router"].T                                    # (..., E)
     # stable top-k with lowest-index tie-break
     order = torch.argsort(-logits, dim=-1, stable=True)[..., :k]
+    if MOE_FORCED_SEL is not None:
+        forced = next(MOE_FORCED_SEL).long().reshape(order.shape)
+        kth = torch.gather(logits, -1, order)[..., k - 1]
+        worst = torch.gather(logits, -1, forced).amin(-1)
+        if MOE_FORCED_DEFICIT is not None:
+            MOE_FORCED_DEFICIT.append((kth - worst).clamp_min(0).reshape(-1).clone())
+        order = forced
+    if MOE_CHOSEN is not None:
+        MOE_CHOSEN.append(order.reshape(-1, k).clone())
     sel = torch.gather(logits, -1, order)
     gates = torch.softmax(sel, dim=-1)
     if MOE_ROUTER_MARGINS is not None:

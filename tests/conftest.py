@@ -13,6 +13,13 @@ os.environ.setdefault("TRANSFORMERS_OFFLINE", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle is a chain of tiny ops: on a many-core host torch's default thread count (one per logical CPU) makes each of them
+    # slower, not faster (a 1024-step oracle decode: 35 s with 128+ threads, ~6 s with 8-16)
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

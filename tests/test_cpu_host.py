@@ -134,6 +134,37 @@ def test_oracle_reproduces_the_full_length_golden_fixture():
     assert np.allclose((top2[..., 0] - top2[..., 1]).numpy(), z["margin"], atol=1e-5)
 
 
+def test_oracle_moe_routing_can_be_teacher_forced():
+    """The hooks the MoE GPU parity tests use: forcing the oracle's own expert choices back into it changes nothing (deficit 0);
+    a choice outside its top two shows up as a positive deficit and moves the logits."""
+    from yourmt3_amd.config import FFN_MOE
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=16, dec_ffn=FFN_MOE, eos_id=-1)
+    W = make_weights(cfg)
+    _, enc = O.encode(O.synthetic_audio(2, cfg), W, cfg, True)
+    O.MOE_CHOSEN = []
+    try:
+        t0, l0 = O.greedy_decode(enc, W, cfg, 6, True, return_logits=True)
+        own = O.MOE_CHOSEN
+    finally:
+        O.MOE_CHOSEN = None
+    assert len(own) == 6 * cfg.n_dec_layers and own[0].shape == (2, 2)
+
+    def forced_run(choices):
+        O.MOE_FORCED_SEL, O.MOE_FORCED_DEFICIT = iter(choices), []
+        try:
+            t, l = O.greedy_decode(enc, W, cfg, 6, True, return_logits=True)
+            return t, l, torch.stack(O.MOE_FORCED_DEFICIT)
+        finally:
+            O.MOE_FORCED_SEL = O.MOE_FORCED_DEFICIT = None
+
+    t1, l1, d1 = forced_run(own)
+    assert torch.equal(t1, t0) and torch.equal(l1, l0) and float(d1.max()) == 0.0
+    other = [c.clone() for c in own]
+    other[3][0, 1] = (set(range(cfg.n_experts)) - set(other[3][0].tolist())).pop()
+    _, l2, d2 = forced_run(other)
+    assert float(d2.max()) > 0.0 and int((d2 > 0).sum()) == 1 and float((l2 - l0).abs().max()) > 1e-3
+
+
 def test_perceiver_tf_oracle_shape_mixing_and_blob():
     """a9 oracle (build-defined spec): (B, T, F') -> latents (B, T, K, D) -> (B, T, d_model); K is free of T; the spectral
     cross-attention sees one frame, the temporal transformer mixes frames; its attention primitive equals torch's SDPA with
@@ -190,13 +221,15 @@ def test_shard_ranges_cover_every_segment_once():
 _WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, sys.argv[1])
-from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens
+from yourmt3_amd.dist import init_distributed, shard_range, all_gather_tokens, gather_floats
 rank, world, _ = init_distributed(int(os.environ["WORLD_SIZE"]))
 n = int(sys.argv[2])
 lo, hi = shard_range(n, rank, world)
 full = (torch.arange(n * 3 * 5, dtype=torch.int32).view(n, 3, 5) * 7) % 1000
 out = all_gather_tokens(full[lo:hi].clone(), world, n_segments=n)
 assert torch.equal(out, full), (rank, out.shape)
+stats = gather_floats([rank + 0.5, 10.0 * rank], world)          # bench.py's per-rank times travel this way
+assert stats == [[r + 0.5, 10.0 * r] for r in range(world)], stats
 torch.distributed.barrier()
 print("rank", rank, "ok")
 """
@@ -210,6 +243,19 @@ def test_all_gather_world_size_2_gloo(tmp_path, n):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
+@pytest.mark.parametrize("n", [61, 5])
+def test_all_gather_world_size_8_gloo_ragged(tmp_path, n):
+    """The driver's 8-GPU shape on CPU: eight ranks, ragged shards (61 segments: seven ranks of 8 and one of 5; 5 segments: three
+    ranks own nothing and contribute padding only), ids back in segment order on every rank, per-rank stats gathered."""
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + n), WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
 
 

@@ -445,11 +445,16 @@ def test_decode_matches_oracle_over_all_1024_positions(variant, env, monkeypatch
     assert late.max().item() < 0.06 and late.mean().item() < 6e-3
     free = m.decode(e, 1024).cpu()
     _check_stream_prefix(free, L["ref_t"], _margin(L["ref_l"]))
-    ora_t, ora_l = O.greedy_decode(L["enc"], L["W"], cfg, 1024, True, forced=free, return_logits=True)
-    safe = _margin(ora_l) >= TAU
-    rec2 = {"tau": TAU, "steps": int(safe.numel()), "safe_fraction": float(safe.float().mean()),
-            "ids_differ_where_safe": int((free[safe] != ora_t[safe]).sum()), "ids_differ_below_tau": int((free[~safe] != ora_t[~safe]).sum()),
-            "first_sub_tau_step": [int((~safe[b, 0]).nonzero()[0]) if (~safe[b, 0]).any() else 1024 for b in range(2)]}
+    if "free" in L and torch.equal(free, L["free"]):
+        rec2 = dict(L["free_rec"], same_ids_as="the first variant run in this session, bit for bit")      # (the variants compute the same bits)
+    else:
+        ora_t, ora_l = O.greedy_decode(L["enc"], L["W"], cfg, 1024, True, forced=free, return_logits=True)
+        safe = _margin(ora_l) >= TAU
+        rec2 = {"tau": TAU, "steps": int(safe.numel()), "safe_fraction": float(safe.float().mean()),
+                "ids_differ_where_safe": int((free[safe] != ora_t[safe]).sum()), "ids_differ_below_tau": int((free[~safe] != ora_t[~safe]).sum()),
+                "first_sub_tau_step": [int((~safe[b, 0]).nonzero()[0]) if (~safe[b, 0]).any() else 1024 for b in range(2)]}
+        if "free" not in L:
+            L["free"], L["free_rec"] = free, rec2
     _REPORT[f"full_length_1024_{variant}_free_running_vs_oracle_on_the_same_prefix"] = rec2
     assert rec2["safe_fraction"] >= MIN_SAFE and rec2["ids_differ_where_safe"] == 0, rec2
     assert bool((free[:, :, 512:] != free[:, :, 512:513]).any())           # still a varied stream late in the decode
@@ -527,54 +532,60 @@ def test_unfit_merged_kernel_takes_the_separate_launches(small, monkeypatch):
         m.close()
 
 
-def _moe_case(cfg, n, tol_max, tol_mean, tau, gap=0.005, min_safe=MIN_SAFE, segments=4):
-    """Teacher-forced MoE decode vs the oracle.  (row, step) pairs where some layer's router gap between the 2nd and
-    3rd expert is below `gap` are excluded: there the GPU may legitimately pick the other expert."""
+def _moe_case(cfg, n, tol_max, tol_mean, tau, max_deficit, monkeypatch, min_safe=0.7, segments=4):
+    """Teacher-forced MoE decode vs the oracle at EVERY step.  Routing is discrete: where the 2nd and 3rd router logits are closer than
+    the numerical noise, the HIP path may legitimately pick another expert than the oracle, which moves that step's logits by ~0.2.
+    Rounds 1-2 excluded such (row, step) pairs by a router-gap threshold (and so covered 52 % of the fp8 steps).  Now the router's
+    choices are recorded (debug hook ymt3_debug_moe_trace) and fed to the ORACLE: each choice must lie within `max_deficit` of the
+    oracle's own top-2 cut (a legitimate near-tie), and then logits and ids are compared at every step, with the usual argmax margin."""
+    monkeypatch.setenv("YMT3_DEBUG_HOOKS", "1")
     m = _model(cfg, max_batch=segments)
+    monkeypatch.delenv("YMT3_DEBUG_HOOKS")
     a = O.synthetic_audio(segments, cfg)
     _, enc = O.encode(a, m.weights, cfg, True)
-    O.MOE_ROUTER_MARGINS = []
-    try:
-        ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, n, True, return_logits=True)
-        gaps = torch.stack(O.MOE_ROUTER_MARGINS).view(n, cfg.n_dec_layers, segments).amin(1).T      # (rows, steps)
-    finally:
-        O.MOE_ROUTER_MARGINS = None
-    got_t, got_l = m.decode(enc.bfloat16().cuda(), n, forced=ref_t.cuda(), return_logits=True)
-    name = f"moe_fp8{cfg.moe_fp8}_{n}_steps"
-    # what the thresholds do to the coverage, and whether any covered id differs: recorded for every (tau, gap) pair looked at
-    err = (got_l.cpu() - ref_l).abs().amax(-1)[:, 0]                                             # (rows, steps)
-    sweep = []
-    for g_ in (0.0, 0.002, 0.005, 0.01, 0.02):
-        st = gaps >= g_
-        for t_ in (0.03, 0.05, 0.065, 0.08):
-            sf = (_margin(ref_l)[:, 0] >= t_) & st
-            sweep.append({"gap": g_, "tau": t_, "covered": round(float(sf.float().mean()), 4), "ids_differ": int((got_t.cpu()[:, 0][sf] != ref_t[:, 0][sf]).sum()),
-                          "logits_max_abs_where_stable": round(float(err[st].max()), 5) if st.any() else None})
-    stable = (gaps >= gap)[:, None, :]                                                        # (B, 1, steps)
-    rec = _check_ids(name, got_t, ref_t, ref_l, got_l, tau=tau, stable=stable, tol_max=tol_max, tol_mean=tol_mean, min_safe=min_safe, curve=32)
-    rec["router_gap"] = gap
-    rec["stable_fraction"] = float(stable.float().mean())
-    rec["threshold_sweep"] = sweep
+    feed = O.greedy_decode(enc, m.weights, cfg, n, True)                     # the oracle's own stream (its own routing): the tokens both sides are fed
+    trace = m.moe_trace(n)
     e = enc.bfloat16().cuda()
+    got_t, got_l = m.decode(e, n, forced=feed.cuda(), return_logits=True)
+    sel = trace.cpu()                                                        # (steps, layers, rows, 2)
+    assert int(sel.min()) >= 0 and int(sel.max()) < cfg.n_experts and bool((sel[..., 0] != sel[..., 1]).all())
+    O.MOE_FORCED_SEL = iter([sel[t, l] for t in range(n) for l in range(cfg.n_dec_layers)])
+    O.MOE_FORCED_DEFICIT = []
+    try:
+        ref_t, ref_l = O.greedy_decode(enc, m.weights, cfg, n, True, forced=feed, return_logits=True)
+        deficit = torch.stack(O.MOE_FORCED_DEFICIT)                          # (steps * layers, rows)
+    finally:
+        O.MOE_FORCED_SEL = None
+        O.MOE_FORCED_DEFICIT = None
+    name = f"moe_fp8{cfg.moe_fp8}_{n}_steps_routing_teacher_forced"
+    rec = _check_ids(name, got_t, ref_t, ref_l, got_l, tau=tau, tol_max=tol_max, tol_mean=tol_mean, min_safe=min_safe, curve=32)
+    rec["router_choices"] = int(deficit.numel())
+    rec["router_choices_outside_the_oracle_top2"] = int((deficit > 0).sum())
+    rec["max_router_deficit"] = float(deficit.max())
+    assert rec["max_router_deficit"] <= max_deficit, rec                   # every differing choice was a near-tie
     assert torch.equal(m.decode(e, n), m.decode(e, n))        # routing + grouped GEMM are reproducible
+    _lib_check = m._lib.ymt3_debug_moe_trace(m._handle, None, 0, 0)
+    assert _lib_check == 0
     return m
 
 
-def test_moe_decoder_ffn_matches_oracle():
+def test_moe_decoder_ffn_matches_oracle(monkeypatch):
     """a11 (build-defined spec, parity unpinned w.r.t. the reference): router -> top-2 -> expert FFNs -> gated sum; 144 positions."""
     from yourmt3_amd.config import FFN_MOE
     cfg = YMT3Config(segment_samples=8191, max_decode_len=160, dec_ffn=FFN_MOE, eos_id=-1)
-    m = _moe_case(cfg, 144, 0.06, 6e-3, TAU)
+    m = _moe_case(cfg, 144, 0.06, 6e-3, TAU, 0.01, monkeypatch, min_safe=MIN_SAFE)
     assert "dec.0.router" in m.weights and m.weights["dec.0.wi"].shape == (8 * 2048, 512)
     m.close()
 
 
-def test_moe_fp8_expert_gemms_match_oracle():
+def test_moe_fp8_expert_gemms_match_oracle(monkeypatch):
     """BASELINE configs[4]: expert GEMMs on OCP e4m3 MFMA (per-expert weight scale, per-row activation scale); 144 positions.
-    Tolerance a little above the bf16 one: a hidden value that rounds to the neighbouring bf16 moves its row's fp8 scale."""
+    Tolerances above the bf16 ones: an fp8 rounding step is 16 bf16 steps, so the same ~1e-3 relative disagreement between two
+    implementations moves an fp8 operand 16x as far when it flips a rounding (logits max 0.08, mean 8e-3; measured 0.036 / 5.9e-3),
+    and TAU = 0.08 stays a little over twice the measured maximum."""
     from yourmt3_amd.config import FFN_MOE
     cfg = YMT3Config(segment_samples=8191, max_decode_len=160, dec_ffn=FFN_MOE, moe_fp8=1, eos_id=-1)
-    m = _moe_case(cfg, 144, 0.08, 8e-3, 0.08, gap=0.02, min_safe=0.4)
+    m = _moe_case(cfg, 144, 0.08, 8e-3, 0.08, 0.04, monkeypatch)
     assert m.weights["dec.0.wi_q8"].dtype == torch.uint8 and "dec.0.wi" not in m.weights
     m.close()
 
@@ -716,8 +727,16 @@ def test_perceiver_tf_encoder_matches_oracle():
         assert enc_ref.shape == (3, cfg.n_frames, cfg.d_model)
         enc = m.encode(m.logmel(a.cuda()))
         d = (enc.float().cpu() - enc_ref).abs()
-        _REPORT[f"perceiver_tf_enc_K{n_lat}"] = {"enc_max_abs": float(d.max()), "enc_mean_abs": float(d.mean())}
-        assert d.max().item() <= 0.0625 and d.mean().item() <= 4e-3, (n_lat, d.max().item(), d.mean().item())
+        # How far may two correct bf16 implementations of THIS model differ?  The oracle evaluated a second time with every sum in
+        # double (same rounding points, oracle/perceiver_oracle.py::in_double) differs from its fp32 self by mean 3.7e-3 / max 0.031
+        # for 3 blocks of 32 latents, 2.0e-3 / 0.016 for one block (the T5 encoder: 1.6e-3): 18 narrow (d = 128) sub-layers amplify
+        # a last-bit difference in a sum to about one final bf16 rounding in every second output value.  The HIP path is held to
+        # 1.25 x that intrinsic figure (measured: 1.01 x), and to the absolute cap of the T5 encoder's test on the maximum.
+        from oracle.perceiver_oracle import encoder_perceiver_tf, in_double
+        intrinsic = (encoder_perceiver_tf(mel_ref.double(), in_double(m.weights), cfg, True).float() - enc_ref).abs()
+        _REPORT[f"perceiver_tf_enc_K{n_lat}"] = {"enc_max_abs": float(d.max()), "enc_mean_abs": float(d.mean()),
+                                                 "oracle_fp32_vs_fp64_sums_max_abs": float(intrinsic.max()), "oracle_fp32_vs_fp64_sums_mean_abs": float(intrinsic.mean())}
+        assert d.max().item() <= 0.0625 and d.mean().item() <= 1.25 * intrinsic.mean().item() + 1e-4, (n_lat, d.max().item(), d.mean().item(), intrinsic.mean().item())
         assert torch.equal(m.encode(m.logmel(a[1:2].cuda()))[0], enc[1])          # a segment alone == inside the batch
         if n_lat == 32:
             t5cfg = cfg.with_(encoder_type=0, n_enc_layers=6)

@@ -998,6 +998,9 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
         float* dst = logits_out + ((size_t)r * n_steps + col) * V;
         for (int i = tid; i < V; i += 256) dst[i] = row[i];
     }
+    // the per-step kernel's arrival counters (dec_step.hip), left at zero for the next step's launch
+    if (a.zero_sync)
+        for (int i = blockIdx.x * 256 + tid; i < a.zero_lines; i += gridDim.x * 256) a.zero_sync[(size_t)i * CHAIN_LINE] = 0u;
     // the last workgroup to finish advances the position; every workgroup has read `t` by then
     __syncthreads();
     if (tid == 0) {

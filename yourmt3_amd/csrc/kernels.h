@@ -141,6 +141,7 @@ struct ChainArgs {
                                 // preceding cross-attention launch), then the sticky abort word on a line of its own
     unsigned* host_abort;       // pinned host word, set with the abort (the host refuses further calls)
     unsigned long long* stamp;
+    unsigned* sync_abort;       // dec_step.hip only: the sticky abort word (the chain launch finds it at sync + CHAIN_ABORT_WORD)
 };
 constexpr int CHAIN_LINE = 32;                                  // 32-bit words per 128-byte line
 constexpr int CHAIN_COUNTERS = 3 * 4 * 8;
@@ -151,6 +152,34 @@ bool dec_chain_fits(int n_cus);                 // occupancy x CUs covers the ch
 bool dec_attention_pair_fits(int n_cus);        // the same for the attention pair at 64 rows
 int launch_dec_chain(const ChainArgs& c, hipStream_t stream);       // 0 launched, < 0: not this kernel's shape
 int launch_chain_poison(const unsigned* sync, int32_t* tokens, long long n, hipStream_t stream);   // tokens = INT32_MIN if the chain aborted
+
+// One decode step's layers as ONE launch (dec_step.hip): per layer the attention pair and the GEMM chain, handed over inside the kernel.
+struct StepLayer {
+    const bf16_t *wo, *wq_c, *wo_c, *wi, *wo2, *w3;    // w3: the next layer's wqkv, or lm_head after the last layer
+    const float *ln2, *ln3, *gain3;                      // gain3: the next layer's ln1, or ln_f
+    const bf16_t *kself, *vself;                         // this layer's self-attention cache [R][H][L][64]
+    const bf16_t *kcross, *vcross;                       // its cross-attention K/V [B][H][T][64]
+    bf16_t *knext, *vnext;                               // the next layer's cache (the QKV stage appends to it)
+    int N3, last;                                        // 3 * 512, or the vocabulary after the last layer
+};
+struct StepArgs {
+    // (dec_step_kernel reads this struct straight from its kernel-argument segment, per layer: common fields first, layers last)
+    int n_layers, R, T, L, ssq_stride;
+    float eps;
+    bf16_t* q; bf16_t* attn; float* opart; float* h; float* ssq; bf16_t* dff; float* logits;
+    const float* bias;                                   // [H][L] self-attention bias by distance
+    const DecodeShared* shared; const int* row_pos;
+    unsigned* sync;                                      // [(n_layers + 1)][STEP_SYNC_LINES_PER_LAYER] counter lines, zero at entry (the argmax kernel zeroes them)
+    unsigned* pair_rows;                                 // [R][2] self-resetting row counters (as the attention pair's)
+    unsigned* abort_word; unsigned* host_abort;
+    StepLayer layer[8];
+};
+// per layer: the chain's 96 counter lines, then attn_done [4 row tiles][8 replicas], then qkv_done [4 row tiles][8 heads]
+constexpr int STEP_SYNC_LINES_PER_LAYER = 3 * 4 * 8 + 32 + 32;
+constexpr int STEP_SYNC_LINES = 9 * STEP_SYNC_LINES_PER_LAYER;
+int init_step_kernel();
+bool dec_step_fits(int n_cus);
+int launch_dec_step(const StepArgs& s, hipStream_t stream);
 
 enum DecGemmMode { DG_NORM_QKV_CACHE = 0, DG_NORM_BF16 = 1, DG_NORM_BF16_RELU = 2, DG_NORM_LOGITS = 3, DG_RESID = 4 };
 int init_decode_kernels();
@@ -221,6 +250,8 @@ struct ArgmaxArgs {
     int* row_pos;               // [R]
     const long long* row_out;   // [R]
     unsigned long long* stamp;  // measurement: as DecGemmArgs::stamp
+    unsigned* zero_sync;        // or null: counter lines (CHAIN_LINE words each) to leave zeroed for the next step's dec_step_kernel
+    int zero_lines;
 };
 int launch_argmax_embed(const ArgmaxArgs& a, hipStream_t stream);
 // tokens_out[r][from .. n_steps) = pad for rows [row0, row0 + R): the tail of a decode that stopped early
@@ -251,6 +282,9 @@ struct MoeArgs {
     float* y;                   // [2R][d_model] gate-scaled expert outputs by pair
     int row0, R, E, top_k, d_model, d_ff;
     float eps;
+    // debug hook ymt3_debug_moe_trace (null otherwise): the router also records its choices, [step][layer][row][2] int32, so a test can
+    // teacher-force the ORACLE's routing with them and check every choice was a legitimate near-tie instead of excluding such steps
+    int32_t* sel_trace; const DecodeShared* shared; int layer, n_layers, trace_rows, trace_steps;
 };
 int init_moe_kernels();
 int launch_moe_stage(int stage, const MoeArgs& a, hipStream_t stream);

@@ -110,6 +110,13 @@ __global__ __launch_bounds__(512) void moe_router_kernel(const float* __restrict
         const float t = __expf(second - best);
         a.sel[2 * r] = e0; a.sel[2 * r + 1] = e1;
         a.gate[2 * r] = 1.0f / (1.0f + t); a.gate[2 * r + 1] = t / (1.0f + t);
+        if (a.sel_trace) {                                      // debug hook only
+            const int st = a.shared->step - a.shared->step0;
+            if (st >= 0 && st < a.trace_steps && r < a.trace_rows) {
+                int32_t* dst = a.sel_trace + (((size_t)st * a.n_layers + a.layer) * a.trace_rows + r) * 2;
+                dst[0] = e0; dst[1] = e1;
+            }
+        }
     }
 }
 

@@ -119,6 +119,8 @@ struct ymt3_ctx {
     bool force_2wave = false;               // YMT3_SELF_ATTN_2WAVE=1 at create (test knob): the many-row 2-wave self-attention at any row count
     bool attn_pair = true;                  // a layer's self- and cross-attention as one launch (decode.hip: dec_attn_pair_kernel; YMT3_NO_ATTN_PAIR=1: two)
     unsigned* pair_rows = nullptr;          // [maxR <= 64][2] counter lines of that kernel (zero between launches)
+    bool step_kernel = true;                // a step's six layers as ONE launch (dec_step.hip; YMT3_NO_STEP_KERNEL=1: attention pair + GEMM chain per layer)
+    unsigned* step_sync = nullptr;          // [STEP_SYNC_LINES] counter lines of that kernel (zeroed by the step's argmax kernel / before a decode call)
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
     size_t prof_span_idx = 0;
@@ -128,6 +130,8 @@ struct ymt3_ctx {
     int* host_flag = nullptr;               // pinned, for that check
     bool debug_hooks = false;               // YMT3_DEBUG_HOOKS=1 at create: ymt3_debug_decode_start is accepted
     int prof_step0 = 0;                     // ymt3_debug_decode_start: the next decode call begins at this position (one shot)
+    int32_t* moe_trace = nullptr;           // ymt3_debug_moe_trace: caller's [steps][layers][rows][2] buffer the MoE router records its choices in
+    int moe_trace_steps = 0, moe_trace_rows = 0;
     std::vector<hipEvent_t> prof_ev;        // pairs
     std::vector<int> prof_cls;
     // measurement (YMT3_STAMP=1): per-workgroup wall-clock stamps of the decode-step kernels, slot = launch order in the step
@@ -147,7 +151,7 @@ static unsigned long long* next_stamp(ymt3_ctx* c, int cls, int grid) {
     return c->stamp_buf + (size_t)i * STAMP_WGS * 2;
 }
 
-enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_CHAIN, PC_ATTN_PAIR, PC_COUNT };
+enum { PC_QKV = 0, PC_SELF_ATTN, PC_SELF_O, PC_CROSS_Q, PC_CROSS_ATTN, PC_CROSS_O, PC_FFN_WI, PC_FFN_WO, PC_LM_HEAD, PC_ARGMAX, PC_SPAN, PC_CHAIN, PC_ATTN_PAIR, PC_STEP, PC_COUNT };
 
 struct ProfScope {
     ymt3_ctx* c; hipStream_t s; bool on;
@@ -362,6 +366,13 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
         const bool init_ok = init_chain_kernels() == 0;
         c->gemm_chain = !env1("YMT3_NO_GEMM_CHAIN") && init_ok && !env1("YMT3_TEST_CHAIN_UNFIT") && dec_chain_fits(prop.multiProcessorCount);
         c->attn_pair = !env1("YMT3_NO_ATTN_PAIR") && init_ok && !env1("YMT3_TEST_PAIR_UNFIT") && dec_attention_pair_fits(prop.multiProcessorCount);
+        // ... and the per-step kernel (all six layers in one launch: 512 workgroups of 76 KB) where both of the above are in use
+        c->step_kernel = c->gemm_chain && c->attn_pair && !env1("YMT3_NO_STEP_KERNEL") && !env1("YMT3_TEST_STEP_UNFIT") && init_step_kernel() == 0 &&
+                         dec_step_fits(prop.multiProcessorCount);
+        if (c->step_kernel) {
+            if (dev_alloc(c, (void**)&c->step_sync, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned))) return YMT3_ERR_HIP;
+            HIP_TRY(hipMemset(c->step_sync, 0, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned)));
+        }
         if (c->gemm_chain || c->attn_pair) {
             if (dev_alloc(c, (void**)&c->chain_sync, CHAIN_SYNC_WORDS * sizeof(unsigned))) return YMT3_ERR_HIP;
             HIP_TRY(hipMemset(c->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
@@ -452,7 +463,7 @@ extern "C" int ymt3_create(const ymt3_config* cfg, const void* blob, size_t nbyt
 // nothing of this handle is still running.  Counters, abort words and the cached step graphs (they hold merged launches) are reset; the
 // separate launches compute the same bits, so the handle goes on working.
 static int merged_fallback(ymt3_ctx* h) {
-    h->gemm_chain = h->attn_pair = false;
+    h->gemm_chain = h->attn_pair = h->step_kernel = false;
     ++h->fallback_count;
     h->forced_abort = false;
     for (auto& kv : h->step_graphs) {
@@ -462,6 +473,7 @@ static int merged_fallback(ymt3_ctx* h) {
     h->step_graphs.clear();
     if (h->chain_sync) HIP_TRY(hipMemset(h->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
     if (h->pair_rows) HIP_TRY(hipMemset(h->pair_rows, 0, (size_t)64 * 2 * CHAIN_LINE * sizeof(unsigned)));
+    if (h->step_sync) HIP_TRY(hipMemset(h->step_sync, 0, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned)));
     HIP_TRY(hipDeviceSynchronize());
     if (h->chain_host_abort) *h->chain_host_abort = 0u;
     return YMT3_OK;
@@ -700,6 +712,8 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     // attention pair (decode.hip: dec_attn_pair_kernel): a layer's two attention kernels as one launch wherever the folded
     // O-projection and the fused query projection apply to one channel of up to 64 rows (dense or MoE FFN alike)
     const bool pair_ok = h->attn_pair && h->pair_rows && merged_regime;
+    // the per-step kernel (dec_step.hip): layer 0's QKV projection, then ALL layers' attention pairs and GEMM chains as one launch
+    const bool stepk = h->step_kernel && h->step_sync && chain && pair_ok && k.n_dec_layers <= 8 && h->T <= 0xfff;
     h->step_merged = chain || pair_ok;
     bool qkv_done = false, lm_done = false;         // the previous layer's chain launch already did this layer's QKV / the lm_head
     for (int l = 0; l < k.n_dec_layers; ++l) {
@@ -721,6 +735,30 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         }
         qkv_done = false;
         if (pend) { hcur = a.h_out; pend = nullptr; a.pend_y = nullptr; a.h_out = nullptr; }
+        if (stepk) {
+            StepArgs sa{};
+            sa.n_layers = k.n_dec_layers; sa.R = R; sa.T = h->T; sa.L = L; sa.ssq_stride = h->maxR; sa.eps = k.ln_eps;
+            sa.q = h->dq; sa.attn = h->dattn; sa.opart = h->opart; sa.h = hcur; sa.ssq = h->ssq; sa.dff = h->dff; sa.logits = h->logits;
+            sa.bias = bias_dist; sa.shared = shared; sa.row_pos = a.row_pos;
+            sa.sync = h->step_sync; sa.pair_rows = h->pair_rows; sa.abort_word = h->chain_sync + CHAIN_ABORT_WORD; sa.host_abort = h->chain_host_abort;
+            const float* ln_f;
+            GET(h, "dec.ln_f", 0u, const_cast<float**>(&ln_f), (size_t)d);
+            for (int j = 0; j < k.n_dec_layers; ++j) {
+                const bool last = j + 1 == k.n_dec_layers;
+                StepLayer& SL = sa.layer[j];
+                SL.wo = LW[j].wo; SL.wq_c = LW[j].wq_c; SL.wo_c = LW[j].wo_c; SL.wi = LW[j].wi; SL.wo2 = LW[j].wo2;
+                SL.w3 = last ? lm_head : LW[j + 1].wqkv;
+                SL.ln2 = LW[j].ln2; SL.ln3 = LW[j].ln3; SL.gain3 = last ? ln_f : LW[j + 1].ln1;
+                SL.kself = h->kcache + (size_t)j * layer_cache; SL.vself = h->vcache + (size_t)j * layer_cache;
+                SL.kcross = h->ckv + (size_t)(2 * j) * slab; SL.vcross = h->ckv + (size_t)(2 * j + 1) * slab;
+                SL.knext = last ? nullptr : h->kcache + (size_t)(j + 1) * layer_cache; SL.vnext = last ? nullptr : h->vcache + (size_t)(j + 1) * layer_cache;
+                SL.N3 = last ? k.vocab : 3 * inner; SL.last = last ? 1 : 0;
+            }
+            (void)next_stamp(h, PC_STEP, 512);
+            PLAUNCH(PC_STEP, launch_dec_step(sa, s));
+            lm_done = true;
+            break;
+        }
         DecAttnArgs t{};
         t.q = h->dq; t.k = a.kcache; t.v = a.vcache; t.out = h->dattn; t.bias = bias_dist; t.shared = shared; t.row0 = row0;
         t.n_keys_const = 0; t.slab_keys = L; t.rows_per_kv = 1; t.R = R; t.H = H; t.bias_stride = L;
@@ -795,6 +833,8 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             mo.h = hcur; mo.gain = W.ln3; mo.ssq = h->ssq; mo.ssq_stride = h->maxR;
             mo.router = W.router; mo.wi = W.wi; mo.wo = W.wo2; mo.row0 = row0; mo.R = R;
             mo.wi_q8 = W.wi_q8; mo.wo_q8 = W.wo_q8; mo.wi_s = W.wi_s; mo.wo_s = W.wo_s; mo.fp8 = k.moe_fp8;
+            mo.sel_trace = h->slot_mode ? nullptr : h->moe_trace; mo.shared = shared; mo.layer = l; mo.n_layers = k.n_dec_layers;
+            mo.trace_rows = h->moe_trace_rows; mo.trace_steps = h->moe_trace_steps;
             { ProfScope _ps(h, PC_FFN_WI, s); LAUNCH(launch_moe_stage(0, mo, s)); LAUNCH(launch_moe_stage(1, mo, s)); }
             { ProfScope _ps(h, PC_FFN_WO, s); LAUNCH(launch_moe_stage(2, mo, s)); if (!fold_combine) LAUNCH(launch_moe_stage(3, mo, s)); }
             if (fold_combine) pend = mo.y;
@@ -823,6 +863,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&g.embed), (size_t)k.vocab * d);
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&g.chan_embed), (size_t)k.n_channels * d);
     if (h->slot_mode) { g.row_pos = h->row_pos; g.row_out = h->row_out; }
+    if (stepk) { g.zero_sync = h->step_sync; g.zero_lines = k.n_dec_layers * STEP_SYNC_LINES_PER_LAYER; }
     g.stamp = next_stamp(h, PC_ARGMAX, R);
     PLAUNCH(PC_ARGMAX, launch_argmax_embed(g, s));
     return YMT3_OK;
@@ -856,6 +897,7 @@ static int decode_run(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int3
     // chains: contiguous, near-equal row ranges
     int n_chains = (!h->use_graph || prof_stride > 0 || k.dec_ffn == YMT3_FFN_MOE) ? 1 : h->n_chains;   // MoE pair tables are per handle
     if (n_chains > R) n_chains = R;
+    if (h->step_kernel && h->step_sync) HIP_TRY(hipMemsetAsync(h->step_sync, 0, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned), s));
     LAUNCH(launch_decode_init(a, n_chains, n_steps, step0, tokens, forced, logits_out, s));
     h->last_steps = n_steps;
     int row0[9];
@@ -1054,6 +1096,7 @@ extern "C" int ymt3_transcribe_stream(ymt3_handle h, const float* audio_dev, int
     struct ModeGuard { ymt3_ctx* c; ~ModeGuard() { c->slot_mode = false; } } guard{h};
     h->slot_mode = true;
     // loop state: every row starts stopped; admissions start them
+    if (h->step_kernel && h->step_sync) HIP_TRY(hipMemsetAsync(h->step_sync, 0, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned), s));
     LAUNCH(launch_decode_init(a, 1, n_steps, 0, tokens_dev, nullptr, nullptr, s));
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->finished), 1, (size_t)R, s));
     HIP_TRY(hipMemsetAsync(h->row_pos, 0, (size_t)R * sizeof(int), s));
@@ -1222,6 +1265,24 @@ extern "C" int ymt3_debug_force_stage_abort(ymt3_handle h) {
     // left for the poison pass's caller to observe: set it only after the next decode call, as the kernel would during that call
     HIP_TRY(hipMemcpy(h->chain_sync + CHAIN_ABORT_WORD, &one, sizeof(one), hipMemcpyHostToDevice));
     h->forced_abort = true;
+    return YMT3_OK;
+}
+
+extern "C" int ymt3_debug_moe_trace(ymt3_handle h, int32_t* trace_dev, int n_steps, int n_rows) {
+    if (!h) FAIL(YMT3_ERR_ARG, "null handle");
+    if (!h->debug_hooks) FAIL(YMT3_ERR_UNSUPPORTED, "debug hooks are accepted only by a handle created with YMT3_DEBUG_HOOKS=1 in the environment");
+    if (h->cfg.dec_ffn != YMT3_FFN_MOE) FAIL(YMT3_ERR_UNSUPPORTED, "this handle has no MoE router");
+    if (trace_dev && (n_steps <= 0 || n_rows <= 0)) FAIL(YMT3_ERR_ARG, "n_steps=%d n_rows=%d", n_steps, n_rows);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& kv : h->step_graphs) {        // cached step graphs carry the old pointer in their kernel arguments
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    h->step_graphs.clear();
+    h->moe_trace = trace_dev;
+    h->moe_trace_steps = trace_dev ? n_steps : 0;
+    h->moe_trace_rows = trace_dev ? n_rows : 0;
     return YMT3_OK;
 }
 

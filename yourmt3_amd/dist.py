@@ -134,3 +134,17 @@ def all_gather_tokens(tokens: torch.Tensor, world: int, n_segments: int | None =
     if all(s == bmax for s in sizes):
         return out
     return torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], 0)
+
+
+def gather_floats(values: Sequence[float], world: int, device: Optional[torch.device] = None) -> List[List[float]]:
+    """Every rank contributes the same number of floats (timings); every rank gets them back as [rank][i].  Used by bench.py so that
+    rank 0's one JSON line carries every rank's own times (a slow rank or a slow collective is then visible in the line itself)."""
+    mine = torch.tensor(list(values), dtype=torch.float64)
+    if world == 1:
+        return [mine.tolist()]
+    on_gpu = dist.get_backend() == "nccl"
+    if on_gpu:
+        mine = mine.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    out = torch.empty(world * mine.numel(), dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine)
+    return out.view(world, -1).cpu().tolist()

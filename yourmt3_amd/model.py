@@ -173,7 +173,7 @@ class YourMT3:
         return out
 
     PROFILE_CLASSES = ["qkv_cache_gemm", "self_attn", "self_o_gemm", "cross_q_gemm", "cross_attn", "cross_o_gemm",
-                       "ffn_wi_gemm", "ffn_wo_gemm", "lm_head_gemm", "argmax_embed", "unsampled_span", "gemm_chain", "attn_pair"]
+                       "ffn_wi_gemm", "ffn_wo_gemm", "lm_head_gemm", "argmax_embed", "unsampled_span", "gemm_chain", "attn_pair", "step_layers"]
 
     def profile_decode(self, enc: torch.Tensor, n_steps: int, stride: int = 16) -> Dict[str, dict]:
         """Eager decode with HIP events around each kernel of every `stride`-th step (include/ymt3.h)."""
@@ -184,6 +184,14 @@ class YourMT3:
         cnt = (ctypes.c_int32 * 16)()
         _lib.check(self._lib.ymt3_profile_decode(self._handle, _ptr(enc), B, n_steps, stride, _ptr(tokens), ms, cnt, self._stream()))
         return {n: {"ms_total": float(ms[i]), "launches": int(cnt[i])} for i, n in enumerate(self.PROFILE_CLASSES)}
+
+    def moe_trace(self, n_steps: int) -> torch.Tensor:
+        """Debug hook (needs YMT3_DEBUG_HOOKS=1 at construction, MoE decoder): from now on lock-step decode calls record the router's
+        choices in the returned (n_steps, n_dec_layers, max_batch * n_channels, 2) int32 device tensor (-1 where nothing was recorded)."""
+        rows = self.max_batch * self.cfg.n_channels
+        self._moe_trace = torch.full((n_steps, self.cfg.n_dec_layers, rows, 2), -1, device=self.device, dtype=torch.int32)
+        _lib.check(self._lib.ymt3_debug_moe_trace(self._handle, _ptr(self._moe_trace), n_steps, rows))
+        return self._moe_trace
 
     def step_stamps(self):
         """Measurement (needs YMT3_STAMP=1 at construction): per kernel of the last decode step, in launch order:
