@@ -34,8 +34,22 @@ MC3 = YMT3Config(segment_samples=8191, max_decode_len=32, n_channels=3)
 
 
 def _model(cfg, max_batch=4, **kw):
+    """A model whose close() fails the test if a merged decode kernel gave up waiting and the call was silently re-run through the separate
+    launches (include/ymt3.h, ymt3_set_abort_recovery): recovery must never be what makes a parity test pass.  Tests of the recovery
+    itself set `fallback_expected`."""
     from yourmt3_amd.model import YourMT3
-    return YourMT3(cfg, make_weights(cfg, seed=1234), device=0, max_batch=max_batch, **kw)
+    m = YourMT3(cfg, make_weights(cfg, seed=1234), device=0, max_batch=max_batch, **kw)
+    plain_close = m.close
+
+    def close():
+        if getattr(m, "_handle", None) and m._handle.value and not getattr(m, "fallback_expected", False):
+            n = m.merged_fallbacks
+            plain_close()
+            assert n == 0, "a merged decode kernel gave up waiting; the ids came from the fallback path"
+        else:
+            plain_close()
+    m.close = close
+    return m
 
 
 @pytest.fixture(scope="module")
@@ -520,12 +534,15 @@ def test_unfit_merged_kernel_takes_the_separate_launches(small, monkeypatch):
     e = small.encode(small.logmel(a))
     ref_t, ref_l = small.decode(e, 40, return_logits=True)
     for var, gone, kept, sep in (("YMT3_TEST_CHAIN_UNFIT", "gemm_chain", "attn_pair", "cross_o_gemm"),
-                                 ("YMT3_TEST_PAIR_UNFIT", "attn_pair", "gemm_chain", "self_attn")):
+                                 ("YMT3_TEST_PAIR_UNFIT", "attn_pair", "gemm_chain", "self_attn"),
+                                 ("YMT3_TEST_STEP_UNFIT", "step_layers", "attn_pair", "gemm_chain")):      # (the per-step kernel needs both of the others)
         monkeypatch.setenv(var, "1")
+        monkeypatch.setenv("YMT3_STEP_KERNEL", "1")           # asked for, and still not taken where a kernel it needs does not fit
         m = _model(SMALL)
         monkeypatch.delenv(var)
+        monkeypatch.delenv("YMT3_STEP_KERNEL")
         prof = m.profile_decode(e, 16, stride=8)
-        assert prof[gone]["launches"] == 0 and prof[kept]["launches"] > 0 and prof[sep]["launches"] > 0, (var, prof)
+        assert prof[gone]["launches"] == 0 and prof["step_layers"]["launches"] == 0 and prof[kept]["launches"] > 0 and prof[sep]["launches"] > 0, (var, prof)
         t, l = m.decode(e, 40, return_logits=True)
         assert torch.equal(t, ref_t) and torch.equal(l, ref_l), var
         assert m.merged_fallbacks == 0
@@ -841,15 +858,57 @@ def test_attention_pair_is_bit_identical_to_the_two_launches(monkeypatch):
     old.close()
 
 
-def test_profile_hooks(small):
+def test_step_kernel_is_bit_identical_to_the_per_layer_launches(monkeypatch):
+    """Round 3, an OPTION (YMT3_STEP_KERNEL=1; measured slower than the default, profiles/r03_step_kernel.md): a step's six attention pairs and
+    six GEMM chains as ONE launch (dec_step.hip): the attention -> chain and QKV -> attention boundaries are arrival counters + agent-scope
+    data.  Same arithmetic as the 14-launch step: logits and ids must not move by one bit, at full and ragged row tiles, one row, short
+    and long positions (the 384-key block boundary included), row tiles in step and as independent pipelines, lock-step and slot mode."""
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=448)
+    old = _model(cfg, max_batch=64)
+    monkeypatch.setenv("YMT3_STEP_KERNEL", "1")
+    new = _model(cfg, max_batch=64)
+    monkeypatch.setenv("YMT3_STEP_TILES_FREE", "1")
+    free = _model(cfg, max_batch=64)
+    monkeypatch.delenv("YMT3_STEP_TILES_FREE")
+    monkeypatch.delenv("YMT3_STEP_KERNEL")
+    assert new.profile_decode(old.encode(old.logmel(O.synthetic_audio(1, cfg).cuda())), 8, stride=4)["step_layers"]["launches"] == 2
+    for B, n in ((1, 448), (5, 100), (16, 40), (17, 40), (37, 40), (64, 448)):
+        a = O.synthetic_audio(B, cfg, seed=60 + B).cuda()
+        e = new.encode(new.logmel(a))
+        t_new, l_new = new.decode(e, n, return_logits=True)
+        t_old, l_old = old.decode(e, n, return_logits=True)
+        assert torch.equal(t_new, t_old) and torch.equal(l_new, l_old), (B, n)
+        assert int(t_new.min()) >= 0 and new.merged_fallbacks == 0
+        assert torch.equal(new.decode(e, n), t_new)
+        assert torch.equal(free.decode(e, n), t_old) and free.merged_fallbacks == 0
+    a = O.synthetic_audio(11, cfg, seed=79).cuda()
+    assert torch.equal(new.inference_stream(a, slots=6, interval=4, max_token_length=48), old.inference_stream(a, slots=6, interval=4, max_token_length=48))
+    assert torch.equal(new.inference_stream(a, slots=11, interval=16, max_token_length=64), old.inference(a, max_token_length=64))
+    assert torch.equal(free.inference_stream(a, slots=6, interval=4, max_token_length=48), old.inference_stream(a, slots=6, interval=4, max_token_length=48))
+    new.close()
+    free.close()
+    old.close()
+
+
+def test_profile_hooks(small, monkeypatch):
     e = small.encode(small.logmel(O.synthetic_audio(2, SMALL).cuda()))
     prof = small.profile_decode(e, 32, stride=8)
     # a layer's self- and cross-attention are one launch (dec_attn_pair_kernel)
     assert prof["attn_pair"]["launches"] == 4 * SMALL.n_dec_layers and prof["attn_pair"]["ms_total"] > 0 and prof["self_attn"]["launches"] == 0
     # the last layer's GEMM-chain launch ends with lm_head (dec_chain.hip): one chain launch per layer, no lm_head launch of its own
-    assert prof["gemm_chain"]["launches"] == 4 * SMALL.n_dec_layers and prof["lm_head_gemm"]["launches"] == 0
+    assert prof["gemm_chain"]["launches"] == 4 * SMALL.n_dec_layers and prof["lm_head_gemm"]["launches"] == 0 and prof["step_layers"]["launches"] == 0
     assert prof["qkv_cache_gemm"]["launches"] == 4 and prof["ffn_wi_gemm"]["launches"] == 0
     assert prof["unsampled_span"]["launches"] == 3
+    monkeypatch.setenv("YMT3_STEP_KERNEL", "1")
+    m = _model(SMALL)
+    monkeypatch.delenv("YMT3_STEP_KERNEL")
+    prof = m.profile_decode(e, 32, stride=8)
+    # the option: a step as three launches -- layer 0's QKV projection, all six layers (dec_step_kernel, lm_head included), argmax + embedding
+    assert prof["step_layers"]["launches"] == 4 and prof["step_layers"]["ms_total"] > 0
+    assert prof["qkv_cache_gemm"]["launches"] == 4 and prof["argmax_embed"]["launches"] == 4
+    for gone in ("attn_pair", "gemm_chain", "self_attn", "lm_head_gemm", "ffn_wi_gemm"):
+        assert prof[gone]["launches"] == 0, gone
+    m.close()
 
 
 def test_decode_start_debug_hook_is_gated_and_one_shot(small, monkeypatch):
@@ -893,6 +952,7 @@ def test_a_stage_abort_is_recovered_through_the_separate_launches(small, monkeyp
     for mode in ("lockstep", "stream"):
         monkeypatch.setenv("YMT3_DEBUG_HOOKS", "1")
         m = _model(SMALL)
+        m.fallback_expected = True
         monkeypatch.delenv("YMT3_DEBUG_HOOKS")
         assert torch.equal(m.inference(a, max_token_length=24), ref) and m.merged_fallbacks == 0
         assert m.profile_decode(e, 8, stride=4)["attn_pair"]["launches"] > 0
@@ -901,7 +961,7 @@ def test_a_stage_abort_is_recovered_through_the_separate_launches(small, monkeyp
         assert torch.equal(got, ref), mode                        # the aborted call itself returns the right ids
         assert m.merged_fallbacks == 1
         prof = m.profile_decode(e, 8, stride=4)                   # ... and the handle now runs the separate launches
-        assert prof["attn_pair"]["launches"] == 0 and prof["gemm_chain"]["launches"] == 0 and prof["self_attn"]["launches"] > 0
+        assert prof["step_layers"]["launches"] == 0 and prof["attn_pair"]["launches"] == 0 and prof["gemm_chain"]["launches"] == 0 and prof["self_attn"]["launches"] > 0
         t, l = m.decode(e, 24, return_logits=True)
         assert torch.equal(t, ref_t) and torch.equal(l, ref_l)
         assert torch.equal(m.inference_stream(a, max_token_length=24, slots=2, interval=4), ref)
@@ -916,6 +976,7 @@ def test_a_stage_abort_without_the_end_of_call_wait(monkeypatch):
     from yourmt3_amd import _lib
     monkeypatch.setenv("YMT3_DEBUG_HOOKS", "1")
     m = _model(SMALL)
+    m.fallback_expected = True
     monkeypatch.delenv("YMT3_DEBUG_HOOKS")
     a = O.synthetic_audio(2, SMALL).cuda()
     ok = m.inference(a, max_token_length=8)
@@ -952,6 +1013,16 @@ def test_step_stamps_hook(small, monkeypatch):
     assert 20.0 < rows[-1][5] < 5000.0                        # one step: tens of microseconds to a few hundred
     raw = m.kernel_stamps(1, rows[1][1])
     assert raw.shape == (rows[1][1], 2) and (raw[:, 1] >= raw[:, 0]).all()
+    m.close()
+    monkeypatch.setenv("YMT3_STAMP", "1")
+    monkeypatch.setenv("YMT3_STEP_KERNEL", "1")
+    m = _model(SMALL)
+    monkeypatch.delenv("YMT3_STAMP")
+    monkeypatch.delenv("YMT3_STEP_KERNEL")
+    assert torch.equal(m.inference(a.cuda(), max_token_length=8), plain)
+    rows = m.step_stamps()
+    assert [r[0] for r in rows] == ["qkv_cache_gemm", "step_layers", "argmax_embed"]          # the option: 3 launches per step
+    assert all(r[1] > 0 and r[2] <= r[4] <= r[5] for r in rows)
     m.close()
 
 

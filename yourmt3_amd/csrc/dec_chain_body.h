@@ -7,6 +7,11 @@
 #ifndef YMT3_TID
 #define YMT3_TID threadIdx.x
 #endif
+// What a poll loop does between two looks at its counter: nothing in the launch form of the chain (its workgroups have nothing else on their
+// CU); dec_step.hip sleeps a little, because its pollers share CUs and the memory side with workgroups that stream K/V
+#ifndef YMT3_POLL_PAUSE
+#define YMT3_POLL_PAUSE do { } while (0)
+#endif
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int DKV = 64;
@@ -74,6 +79,7 @@ __device__ __forceinline__ void chain_wait(unsigned* sync, int boundary, int mt,
         unsigned long long t0 = 0;
         unsigned polls = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            YMT3_POLL_PAUSE;
             if ((++polls & 63u) == 0u) {
                 const unsigned long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
@@ -93,6 +99,7 @@ __device__ __forceinline__ void counter_wait(const unsigned* cnt, unsigned targe
         unsigned long long t0 = 0;
         unsigned polls = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            YMT3_POLL_PAUSE;
             if ((++polls & 63u) == 0u) {
                 const unsigned long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
@@ -283,6 +290,8 @@ struct ChainInLaunch {
     const unsigned* attn_done;      // this workgroup's replica of its row tile's arrival counter
     unsigned attn_target;
     unsigned* qkv_done;             // [4 row tiles][8 heads] lines of CHAIN_LINE words; null after the last layer
+    unsigned long long* mark;       // measurement or null: [0] the row tile's attention has arrived
+    int tiles_free;                 // 0: every row tile signals the lines of row tile 0 (dec_step.hip: the tiles move in step)
 };
 template <int MODE3, bool W2F, bool INL = false>
 __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, const bf16_t* __restrict__ pW1, const bf16_t* __restrict__ pW2,
@@ -331,18 +340,13 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
         const int mq = row0 + mt3 * 16 + tid / 16;
         step = c.row_pos ? c.row_pos[mq < m_end ? mq : m_end - 1] : c.shared->step;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    u32x4 w1[G1::NIW], w2[W2F ? G2::KS : G2::NIW], w3[G1::NIW];
-    load_w<512, 2>(pW1, nt1 * 32, w1);
-    if constexpr (W2F) load_w_frag<2048>(pW2, nt0 * 16, w2);
-    else load_w<2048, 1>(pW2, nt0 * 16, w2);
-    load_w<512, 2>(pW3, nt3 * 32, w3);
-    const f32x4 g1 = norm_gain(c.gain1), g3 = norm_gain(c.gain3);
-    __builtin_amdgcn_sched_barrier(0);
-    CH_STAMP_IN(c);
     if constexpr (INL) {
-        // every weight of the chain is in flight; now the row tile's attention must be complete, then its outputs come in at agent scope
+        // Stage 0's weights are in flight; now the row tile's attention must be complete, then its outputs come in at agent scope, and only
+        // then the later stages' weights are requested (as in the launch form: stage 0's operands first).  (Requesting all weights before the
+        // wait put 147 KB per workgroup in front of the poll -- vector-memory data returns in issue order -- on the critical path of the
+        // workgroup whose own attention half was the tile's last.)
         if (mt < n_mt) counter_wait(in.attn_done, in.attn_target, c.sync_abort, c.host_abort);
+        if (in.mark && YMT3_TID == 0) in.mark[0] = wall_clock64();
         if (has0) {
             const __amdgpu_buffer_rsrc_t rat = raw_rsrc(pAttn);
 #pragma unroll
@@ -360,6 +364,15 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
             }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 w1[G1::NIW], w2[W2F ? G2::KS : G2::NIW], w3[G1::NIW];
+    load_w<512, 2>(pW1, nt1 * 32, w1);
+    if constexpr (W2F) load_w_frag<2048>(pW2, nt0 * 16, w2);
+    else load_w<2048, 1>(pW2, nt0 * 16, w2);
+    load_w<512, 2>(pW3, nt3 * 32, w3);
+    const f32x4 g1 = norm_gain(c.gain1), g3 = norm_gain(c.gain3);
+    __builtin_amdgcn_sched_barrier(0);
+    CH_STAMP_IN(c);
 
     float2 o0 = make_float2(0.f, 0.f);
     if (has0) {
@@ -436,7 +449,8 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
     if constexpr (INL && MODE3 == DG_NORM_QKV_CACHE) {
         // the tile's q / k / v columns are one head's: 32-column tiles 2h, 2h + 1 of each of the three 512-column blocks
         if (mt < n_mt) {                                                  // (workgroup-uniform: counter_signal holds a barrier)
-            if (has3) counter_signal(in.qkv_done + (size_t)(mt3 * 8 + ((nt3 & 15) >> 1)) * CHAIN_LINE, 1, 0);
+            // (tiles in step: the head's line of EVERY row tile gets the arrival -- four lanes, lines 8 apart -- so that a line has 16 pollers, not 64)
+            if (has3) counter_signal(in.qkv_done + (size_t)((in.tiles_free ? mt3 * 8 : 0) + ((nt3 & 15) >> 1)) * CHAIN_LINE, in.tiles_free ? 1 : 4, 8 * CHAIN_LINE);
         }
     }
     CH_STAMP_OUT(c);

@@ -39,8 +39,10 @@ __device__ __forceinline__ unsigned step_tid() {
     return t;
 }
 #define YMT3_TID step_tid()
+#define YMT3_POLL_PAUSE __builtin_amdgcn_s_sleep(4)
 #include "dec_chain_body.h"
 
+constexpr int STEP_MARK0 = 1024, STEP_MARKS = 24;     // measurement: 4 marks per layer per workgroup behind the [512][2] entry / exit stamps (a stamp slot holds 16384 words)
 constexpr int WO_BYTES = 8 * 64 * 128;          // the head's 64 k of all 512 wo rows, per wave 8 KB
 constexpr int STEP_LDS = (8 * 16 * 16 + 16) * 4 + 8 * 16 * (2048 / 8 * 2 + 16);     // chain stage 2 (W2F) = 75 840 B; attention needs 64 KB + 4.4 KB
 static_assert(STEP_LDS >= WO_BYTES + 5120, "attention's statics live behind the wo strip");
@@ -48,15 +50,16 @@ static_assert(STEP_LDS <= 80 * 1024, "two workgroups per CU");
 
 // The argument struct reaches the kernel body through an opaque copy (see dec_step_kernel), so hipcc no longer knows that its pointers are
 // global memory and would emit flat loads / stores (which also count against LDS waits, and in front of which it drains the store queue).
-// Round trip through the global address space: the optimiser propagates it to every access.
+// Each pointer is re-made from its bits as a global-address-space pointer: the optimiser propagates that to every access.
 template <typename T>
 __device__ __forceinline__ T* as_global(T* p) {
-    return (T*)(__attribute__((address_space(1))) T*)p;
+    return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p;
 }
 __device__ __forceinline__ void globalize(StepArgs& s) {
     s.q = as_global(s.q); s.attn = as_global(s.attn); s.opart = as_global(s.opart); s.h = as_global(s.h); s.ssq = as_global(s.ssq);
     s.dff = as_global(s.dff); s.logits = as_global(s.logits); s.bias = as_global(s.bias); s.shared = as_global(s.shared);
     s.row_pos = as_global(s.row_pos); s.sync = as_global(s.sync); s.pair_rows = as_global(s.pair_rows); s.abort_word = as_global(s.abort_word);
+    s.stamp = as_global(s.stamp);
     // (host_abort is pinned host memory: it stays a generic pointer)
 }
 __device__ __forceinline__ void globalize(StepLayer& L) {
@@ -88,6 +91,7 @@ __device__ __forceinline__ void row_wait(unsigned* rows, unsigned* abort_word, u
         unsigned polls = 0;
         bool ok = true;
         while (__hip_atomic_load(arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u) {
+            YMT3_POLL_PAUSE;
             if ((++polls & 63u) == 0u) {
                 const unsigned long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
@@ -111,10 +115,11 @@ __device__ __forceinline__ void row_wait(unsigned* rows, unsigned* abort_word, u
 struct Soft { float m, l, acc[8]; };
 
 // ---- self-attention half of (row r, head h): decode.hip attn_body<SELF, !FUSEQ, 8, OP, PAIR = 1>, statics in the dynamic LDS block.
-// QWAIT: q and the newest cache line were written earlier in this launch (by the previous layer's QKV stage): wait for the head's six
-// tiles after the wo request, read q at agent scope.
-template <bool QWAIT>
-__device__ __forceinline__ void self_half(const StepArgs& s, const StepLayer& L, int r, int h, int n_keys, const AttnLds& lds, const unsigned* qkv_done) {
+// qkv_done != null: q and the newest cache line were written earlier in this launch (by the previous layer's QKV stage): wait for the head's
+// six tiles after the wo request.  q is read at agent scope either way.  (ONE instantiation for all layers: with a second one for layer 0
+// hipcc merged the two tails and drained the store queue -- s_waitcnt vmcnt(0) -- in front of the cross-attention half's counted wait.)
+__device__ __forceinline__ void self_half(const StepArgs& s, const StepLayer& L, int r, int h, int n_keys, const AttnLds& lds, const unsigned* qkv_done,
+                                          unsigned qkv_target, unsigned long long* mark) {
     constexpr int NW = 8, U = 6, H = 8;
     const int tid = YMT3_TID, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,14 +134,9 @@ __device__ __forceinline__ void self_half(const StepArgs& s, const StepLayer& L,
 #pragma unroll
         for (int i = 0; i < 8; ++i) glds16(src + (size_t)i * 8 * H * DKV, lds0 + (unsigned)i * 1024u);
     }
-    u32x4 qp;
-    if constexpr (QWAIT) {
-        counter_wait(qkv_done, 6u, s.abort_word, s.host_abort);
-        const __amdgpu_buffer_rsrc_t rq = raw_rsrc(s.q);
-        qp = ld16_agent(rq, (((r * H + h) * DKV) + sub * 8) * 2);
-    } else {
-        qp = *reinterpret_cast<const u32x4*>(s.q + ((size_t)r * H + h) * DKV + sub * 8);
-    }
+    if (qkv_done) counter_wait(qkv_done, qkv_target, s.abort_word, s.host_abort);
+    if (mark && YMT3_TID == 0) mark[0] = wall_clock64();       // measurement: q is there
+    const u32x4 qp = ld16_agent(raw_rsrc(s.q), (((r * H + h) * DKV) + sub * 8) * 2);
     float m = -1.0e30f, l = 0.f, acc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.f;
@@ -438,7 +438,13 @@ __global__ __launch_bounds__(512, 4) void dec_step_kernel(const DecodeShared* __
     const int b = blockIdx.x;
     const int r = b >> 3, h = b & 7;                    // attention role: (row, head)
     const int tile = b >> 7;                            // this workgroup's row tile, in both roles
-    const int local = b & 127;                          // chain role: column tile `local` of row tile `tile` when local < 64
+    // Chain role: 64 of the tile's 128 workgroups.  Blocks are dealt round-robin over the 8 XCDs and, inside an XCD, over its 32 CUs before a
+    // CU gets its second workgroup (observed placement, speed only): block b sits on CU (b >> 3) & 31 of XCD b & 7, so rows tiles 0 / 2 share
+    // CUs and so do 1 / 3.  Taking the even (b >> 3) of tiles 0 and 1 and the odd ones of tiles 2 and 3 puts every chain tile on a CU of its
+    // own (its 147 KB of weights are what a chain stage waits for); tiles with one column tile stay on one XCD, as in dec_chain_kernel.
+    const int k16 = (b >> 3) & 15;                      // position among the tile's 16 blocks of this XCD
+    const bool chain_role = (k16 & 1) == (tile >> 1);
+    const int local = ((k16 >> 1) << 3) | (b & 7);      // the chain's column tile, 0..63
     const int n_mt = (R + 15) >> 4;
     if (tile >= n_mt) return;                           // (whole row tiles beyond R: nothing waits for them)
     const bool has_attn = r < R;
@@ -446,7 +452,6 @@ __global__ __launch_bounds__(512, 4) void dec_step_kernel(const DecodeShared* __
     const int n_keys = has_attn ? (pRowPos ? pRowPos[r] : pShared->step) + 1 : 0;
     // chain tile index in dec_chain_kernel's encoding: row tile = (t >> 3) & 3, column tile = (t >> 5) * 8 + (t & 7)
     const int t_chain = ((local >> 3) << 5) | (tile << 3) | (local & 7);
-
     // The argument struct is read from the kernel-argument segment itself, per layer, through a pointer the optimiser cannot see through:
     // otherwise every field of every phase is loaded (and the address arithmetic on it done) before the loop and spilled.
     typedef const __attribute__((address_space(4))) char* kernarg_ptr;
@@ -475,31 +480,39 @@ __global__ __launch_bounds__(512, 4) void dec_step_kernel(const DecodeShared* __
         }
         globalize(s);
         globalize(L);
+        if (s.stamp && l == 0 && YMT3_TID == 0) s.stamp[2 * b] = wall_clock64();
         unsigned* sync_l = s.sync + (size_t)l * STEP_SYNC_LINES_PER_LAYER * CHAIN_LINE;
-        unsigned* attn_done = sync_l + (size_t)(CHAIN_COUNTERS + tile * 8) * CHAIN_LINE;                       // 8 replicas
+        // tiles_free: every row tile has counters of its own.  Else all tiles arrive at tile 0's lines and wait for everybody: the four tiles
+        // move through the phases in step, as a sequence of launches would, and a phase's hand-offs are not slowed by another tile's streams
+        unsigned* attn_done = sync_l + (size_t)(CHAIN_COUNTERS + (s.tiles_free ? tile * 8 : 0)) * CHAIN_LINE;    // 8 replicas per tile, or all 32 lines for everybody
         if (has_attn) {
-            if (l == 0) self_half<false>(s, L, r, h, n_keys, lds, nullptr);
-            else self_half<true>(s, L, r, h, n_keys, lds, sync_l + (size_t)(CHAIN_COUNTERS + 32 + tile * 8 + h) * CHAIN_LINE);
+            self_half(s, L, r, h, n_keys, lds, l == 0 ? nullptr : sync_l + (size_t)(CHAIN_COUNTERS + 32 + tile * 8 + h) * CHAIN_LINE, s.tiles_free ? 6u : 6u * n_mt,
+                      s.stamp ? s.stamp + STEP_MARK0 + STEP_MARKS * b + 4 * l : nullptr);
             // the second half counts its loads against the first half's stores: nothing may cross this line
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             cross_half(s, L, r, h, lds);
-            counter_signal(attn_done, 8, CHAIN_LINE);       // (waits for the output line's acknowledgement, then a barrier: the LDS block is free)
+            counter_signal(attn_done, s.tiles_free ? 8 : 32, CHAIN_LINE);       // (waits for the output line's acknowledgement, then a barrier: the LDS block is free)
+            if (s.stamp && YMT3_TID == 0) s.stamp[STEP_MARK0 + STEP_MARKS * b + 4 * l + 1] = wall_clock64();          // mark: this layer's attention left
         }
-        if (local < 64) {
+        if (chain_role) {
             ChainArgs c{};
             c.part = s.opart; c.ssq = s.ssq; c.ssq_stride = s.ssq_stride; c.gain1 = L.ln3; c.gain3 = L.gain3; c.dff = s.dff; c.d_ff = 2048;
             c.N3 = L.N3; c.out_q = s.q; c.kcache = L.knext; c.vcache = L.vnext; c.logits = s.logits; c.H = 8; c.L = s.L;
             c.shared = pShared; c.row_pos = pRowPos; c.row0 = 0; c.R = R; c.eps = s.eps;
             c.sync = sync_l; c.host_abort = s.host_abort; c.sync_abort = s.abort_word; c.stamp = nullptr;
             ChainInLaunch in;
-            in.attn_done = attn_done + (size_t)(b & 7) * CHAIN_LINE;
-            in.attn_target = (unsigned)(rows_in_tile * 8);
+            in.attn_done = attn_done + (size_t)(s.tiles_free ? (b & 7) : ((b >> 3) & 31)) * CHAIN_LINE;
+            in.attn_target = (unsigned)((s.tiles_free ? rows_in_tile : R) * 8);
+            in.tiles_free = s.tiles_free;
             in.qkv_done = sync_l + (size_t)(STEP_SYNC_LINES_PER_LAYER + CHAIN_COUNTERS + 32) * CHAIN_LINE;      // the NEXT layer's lines
+            in.mark = s.stamp ? s.stamp + STEP_MARK0 + STEP_MARKS * b + 4 * l + 2 : nullptr;
             if (L.last) chain_stages<DG_NORM_LOGITS, true, true>(L.wo_c, L.wi, L.wo2, L.w3, s.attn, s.h, 0, R, c, smem, t_chain, in);
             else chain_stages<DG_NORM_QKV_CACHE, true, true>(L.wo_c, L.wi, L.wo2, L.w3, s.attn, s.h, 0, R, c, smem, t_chain, in);
             __syncthreads();                                 // the LDS block goes back to the attention halves
+            if (s.stamp && YMT3_TID == 0) s.stamp[STEP_MARK0 + STEP_MARKS * b + 4 * l + 3] = wall_clock64();      // mark: this layer's chain tile done
         }
+        if (s.stamp && l + 1 == n_layers && (YMT3_TID & 63) == 0) atomicMax(s.stamp + 2 * b + 1, (unsigned long long)wall_clock64());
     }
 }
 

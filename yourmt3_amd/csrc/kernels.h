@@ -166,12 +166,14 @@ struct StepArgs {
     // (dec_step_kernel reads this struct straight from its kernel-argument segment, per layer: common fields first, layers last)
     int n_layers, R, T, L, ssq_stride;
     float eps;
+    int tiles_free, pad_;                                // 1: a row tile waits only for itself (four independent pipelines); 0: the tiles move in step
     bf16_t* q; bf16_t* attn; float* opart; float* h; float* ssq; bf16_t* dff; float* logits;
     const float* bias;                                   // [H][L] self-attention bias by distance
     const DecodeShared* shared; const int* row_pos;
     unsigned* sync;                                      // [(n_layers + 1)][STEP_SYNC_LINES_PER_LAYER] counter lines, zero at entry (the argmax kernel zeroes them)
     unsigned* pair_rows;                                 // [R][2] self-resetting row counters (as the attention pair's)
     unsigned* abort_word; unsigned* host_abort;
+    unsigned long long* stamp;                           // measurement (YMT3_STAMP=1) or null: [grid][2] entry / exit clocks, then 16 marks per workgroup from word 1024
     StepLayer layer[8];
 };
 // per layer: the chain's 96 counter lines, then attn_done [4 row tiles][8 replicas], then qkv_done [4 row tiles][8 heads]

@@ -119,7 +119,8 @@ struct ymt3_ctx {
     bool force_2wave = false;               // YMT3_SELF_ATTN_2WAVE=1 at create (test knob): the many-row 2-wave self-attention at any row count
     bool attn_pair = true;                  // a layer's self- and cross-attention as one launch (decode.hip: dec_attn_pair_kernel; YMT3_NO_ATTN_PAIR=1: two)
     unsigned* pair_rows = nullptr;          // [maxR <= 64][2] counter lines of that kernel (zero between launches)
-    bool step_kernel = true;                // a step's six layers as ONE launch (dec_step.hip; YMT3_NO_STEP_KERNEL=1: attention pair + GEMM chain per layer)
+    bool step_kernel = false;               // a step's six layers as ONE launch (dec_step.hip): YMT3_STEP_KERNEL=1; default: attention pair + GEMM chain per layer
+    bool step_tiles_free = false;           // YMT3_STEP_TILES_FREE=1 (A/B): the step kernel's four row tiles as independent pipelines instead of in step
     unsigned* step_sync = nullptr;          // [STEP_SYNC_LINES] counter lines of that kernel (zeroed by the step's argmax kernel / before a decode call)
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
@@ -367,7 +368,9 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
         c->gemm_chain = !env1("YMT3_NO_GEMM_CHAIN") && init_ok && !env1("YMT3_TEST_CHAIN_UNFIT") && dec_chain_fits(prop.multiProcessorCount);
         c->attn_pair = !env1("YMT3_NO_ATTN_PAIR") && init_ok && !env1("YMT3_TEST_PAIR_UNFIT") && dec_attention_pair_fits(prop.multiProcessorCount);
         // ... and the per-step kernel (all six layers in one launch: 512 workgroups of 76 KB) where both of the above are in use
-        c->step_kernel = c->gemm_chain && c->attn_pair && !env1("YMT3_NO_STEP_KERNEL") && !env1("YMT3_TEST_STEP_UNFIT") && init_step_kernel() == 0 &&
+        // -- measured SLOWER than the per-layer launches (271-296 ms per batch against 247: profiles/r03_step_kernel.md), so it is an option
+        // (YMT3_STEP_KERNEL=1), bit-identical and tested, not the default
+        c->step_kernel = c->gemm_chain && c->attn_pair && env1("YMT3_STEP_KERNEL") && !env1("YMT3_TEST_STEP_UNFIT") && init_step_kernel() == 0 &&
                          dec_step_fits(prop.multiProcessorCount);
         if (c->step_kernel) {
             if (dev_alloc(c, (void**)&c->step_sync, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned))) return YMT3_ERR_HIP;
@@ -413,6 +416,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (const char* mr = getenv("YMT3_DEC_GEMM_MID_ROWS")) c->mid_rows = atoi(mr) < 0 ? -1 : atoi(mr);
     const char* f2 = getenv("YMT3_SELF_ATTN_2WAVE");
     c->force_2wave = f2 && f2[0] == '1';
+    { const char* tf = getenv("YMT3_STEP_TILES_FREE"); c->step_tiles_free = tf && tf[0] == '1'; }
     if (const char* ar = getenv("YMT3_ABORT_RECOVERY")) c->abort_recovery = ar[0] == '0' ? 0 : 1;
     const char* nc = getenv("YMT3_CHAINS");
     if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
@@ -738,6 +742,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
         if (stepk) {
             StepArgs sa{};
             sa.n_layers = k.n_dec_layers; sa.R = R; sa.T = h->T; sa.L = L; sa.ssq_stride = h->maxR; sa.eps = k.ln_eps;
+            sa.tiles_free = h->step_tiles_free ? 1 : 0;
             sa.q = h->dq; sa.attn = h->dattn; sa.opart = h->opart; sa.h = hcur; sa.ssq = h->ssq; sa.dff = h->dff; sa.logits = h->logits;
             sa.bias = bias_dist; sa.shared = shared; sa.row_pos = a.row_pos;
             sa.sync = h->step_sync; sa.pair_rows = h->pair_rows; sa.abort_word = h->chain_sync + CHAIN_ABORT_WORD; sa.host_abort = h->chain_host_abort;
@@ -754,7 +759,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
                 SL.knext = last ? nullptr : h->kcache + (size_t)(j + 1) * layer_cache; SL.vnext = last ? nullptr : h->vcache + (size_t)(j + 1) * layer_cache;
                 SL.N3 = last ? k.vocab : 3 * inner; SL.last = last ? 1 : 0;
             }
-            (void)next_stamp(h, PC_STEP, 512);
+            sa.stamp = next_stamp(h, PC_STEP, ((R + 15) / 16) * 128);
             PLAUNCH(PC_STEP, launch_dec_step(sa, s));
             lm_done = true;
             break;
