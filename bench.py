@@ -98,7 +98,7 @@ def pmc_traffic(cfg, B: int, L: int, paired: bool = False):
     if B != 64 or L != 1024 or cfg.n_channels != 1 or cfg.n_frames != 256:
         return None
     if paired:
-        d = pmc_file("r02_pmc_attn_pair.json")
+        d = pmc_file("r03_pmc_attn_pair.json") or pmc_file("r02_pmc_attn_pair.json")      # (the kernel is round 2's, unchanged)
         return None if d is None else d["attn_pair"]["hbm_bytes_per_launch"]
     d = pmc_file("r02_pmc_decode_attn.json") or pmc_file("r01_pmc_decode_attn.json")
     return None if d is None else d["self_attn"]["hbm_bytes_per_launch"]
@@ -306,14 +306,23 @@ def roofline_block(model, cfg, audio, B, L, stride, sec_per_batch) -> dict:
     torch.cuda.synchronize()
     enc_ms = e0.elapsed_time(e1) / reps
     enc_tflops = encoder_flops_per_segment(cfg) * B / (enc_ms * 1e-3) / 1e12
-    gm = pmc_file("r01_pmc_gemm_mfma.json")
+    gm = pmc_file("r03_pmc_encoder.json")
+    gemm_pmc = None
+    if gm is not None:
+        sect = next((v for k, v in gm.items() if k.startswith("configs[1]")), None)
+        if sect is not None:
+            label = {"gemm_big_kernel<1>": "qkv_gemm", "gemm_big_kernel<2>": "ffn_in_gemm", "gemm_big_kernel<3>": "o_and_ffn_out_gemms", "gemm_big_kernel<4>": "cross_kv_gemm",
+                     "gemm_big_kernel<0>": "mel_projection_gemm", "enc_attn_kernel<256>": "encoder_attention"}
+            gemm_pmc = {lab: rec["mfma_utilisation"] for name, rec in sect["kernels"].items() for key, lab in label.items() if name.startswith(key)}
+            gemm_pmc["all_encoder_side_kernels"] = sect["all_encoder_side_kernels"]["mfma_utilisation"]
     out["mfma_util"] = {
         "encoder_whole": enc_tflops / MFMA_BF16_PEAK_TFLOPS, "encoder_tflops": enc_tflops, "encoder_ms": enc_ms,
         "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
-        "gemm_pmc": None if gm is None else {k.split(" (")[0]: v["mfma_utilisation"] for k, v in gm["kernels"].items()},
+        "gemm_pmc": gemm_pmc,
         "note": "encoder_whole = 10.47 GFLOP x segments / live time of ymt3_encode (front-end excluded; norms, attention and "
-                "epilogues included) / 2.5 PFLOP/s dense bf16; gemm_pmc = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE) "
-                "per GEMM kernel from profiles/r01_pmc_gemm_mfma.json (separate rocprofv3 --pmc passes)",
+                "epilogues included) / 2.5 PFLOP/s dense bf16; gemm_pmc = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) per kernel, "
+                "in situ: separate rocprofv3 --pmc passes around the C host running THIS workload (profiles/r03_pmc_encoder.json, "
+                "scripts/gpu_r03_pmc_encoder.sh); all_encoder_side_kernels = the same ratio over log-mel, norms, attention and GEMMs together",
     }
 
     prof = model.profile_decode(enc, L, stride=stride)
@@ -337,9 +346,12 @@ def roofline_block(model, cfg, audio, B, L, stride, sec_per_batch) -> dict:
     wb = decoder_weight_bytes(cfg)
     # a layer's self- and cross-attention are one launch at this shape (dec_attn_pair_kernel): its bytes are both K/V streams
     paired = "attn_pair" in kern
-    attn_name = "attn_pair" if paired else "self_attn"
+    stepk = "step_layers" in kern          # YMT3_STEP_KERNEL=1: a step's six layers are one launch (all K/V streams + every weight but layer 0's QKV)
+    attn_name = "step_layers" if stepk else ("attn_pair" if paired else "self_attn")
     attn_bytes = sa_bytes + ca_bytes if paired else sa_bytes
-    assert kern[attn_name]["launches"] == n_sampled * cfg.n_dec_layers, (kern[attn_name], n_sampled)
+    if stepk:
+        attn_bytes = cfg.n_dec_layers * (sa_bytes + ca_bytes) + sum(v for k, v in wb.items() if k != "lm_head_gemm") * cfg.n_dec_layers + wb["lm_head_gemm"] - wb["qkv_cache_gemm"]
+    assert kern[attn_name]["launches"] == n_sampled * (1 if stepk else cfg.n_dec_layers), (kern[attn_name], n_sampled)
 
     def hbm(bytes_per_launch, name):
         gbs = bytes_per_launch / (us[name] * 1e-6) / 1e9
@@ -350,11 +362,12 @@ def roofline_block(model, cfg, audio, B, L, stride, sec_per_batch) -> dict:
     shares = {k: us[k] * per_step[k] / step_us for k in kern}
     top = max(shares, key=shares.get)
     kernel_label = {"self_attn": "dec_attn_kernel<true> (decoder self-attention over the KV cache)",
-                    "attn_pair": "dec_attn_pair_kernel (a decoder layer's self-attention over the KV cache + cross-attention over the encoder K/V, one launch)"}
+                    "attn_pair": "dec_attn_pair_kernel (a decoder layer's self-attention over the KV cache + cross-attention over the encoder K/V, one launch)",
+                    "step_layers": "dec_step_kernel (all six decoder layers of a step as one launch: YMT3_STEP_KERNEL=1)"}
     out["roofline"] = {
         "kernel": kernel_label.get(top, top),
         "bound": "hbm", "achieved": sa["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sa["frac"],
-        "traffic": pmc_traffic(cfg, B, L, paired),
+        "traffic": None if stepk else pmc_traffic(cfg, B, L, paired),
         "avg_launch_us": sa["avg_launch_us"], "launches_timed": kern[attn_name]["launches"], "event_pair_overhead_us": 1e3 * pair_ms,
         "eager_step_us": 1e3 * step_true_ms, "share_of_step": sa["share_of_step"],
         "algorithmic_bytes_per_launch": attn_bytes,

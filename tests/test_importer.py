@@ -115,8 +115,12 @@ def test_lightning_shaped_checkpoint_container(tmp_path):
     assert W.keys() == direct.keys() and all(torch.equal(W[k], direct[k]) for k in W)
     bare = str(tmp_path / "bare.pt")
     torch.save({k[len("model."):]: v for k, v in sd.items()}, bare)             # a bare state dict, no prefix
-    W2 = from_checkpoint(bare, CFG)
+    with pytest.raises(ValueError, match="in_proj_names"):                        # no silent all-zero encoder input
+        from_checkpoint(bare, CFG)
+    W2 = from_checkpoint(bare, CFG, allow_zero_in_proj=True)
     assert torch.equal(W2["dec.3.wkv_c"], direct["dec.3.wkv_c"]) and float(W2["in_proj.w"].abs().max()) == 0.0
+    W3 = from_checkpoint(bare, CFG, name_map={"in_proj.w": "pre_encoder.proj.weight", "in_proj.b": "pre_encoder.proj.bias"})   # the same through the table
+    assert torch.equal(W3["in_proj.w"], direct["in_proj.w"])
     with pytest.raises(ValueError, match="d_ff"):
         from_checkpoint(path, CFG.with_(d_ff=1024))
     with pytest.raises(ValueError, match="no T5 encoder"):
@@ -129,3 +133,32 @@ def test_lightning_shaped_checkpoint_container(tmp_path):
     torch.save({"state_dict": sd, "callbacks": Evil()}, str(tmp_path / "evil.ckpt"))
     with pytest.raises(ValueError, match="safe loader"):
         from_checkpoint(str(tmp_path / "evil.ckpt"), CFG)
+
+
+def test_ymt3_plus_shaped_container_round_trips_through_the_rule_table(tmp_path):
+    """The importer is a table (importer.t5_rules + extra_rules): HF T5 names for the T5 tensors, this build's names under `ymt3.` for what
+    T5 has no name for -- the Perceiver-TF encoder, the channel embedding, the MoE router and experts.  A YMT3+-shaped set of weights
+    (Perceiver-TF encoder + 13 channels + MoE decoder) written as a Lightning-shaped container comes back tensor for tensor; the same
+    container imports into the fp8 config (experts quantised at import); a missing tensor is named."""
+    from yourmt3_amd.config import ENC_PERCEIVER_TF, FFN_MOE
+    from yourmt3_amd.importer import extra_rules, from_checkpoint, t5_rules, to_checkpoint
+    from yourmt3_amd.weights import make_weights
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=32, encoder_type=ENC_PERCEIVER_TF, n_enc_layers=0, n_latents=32, ptf_blocks=1,
+                     n_channels=13, dec_ffn=FFN_MOE)
+    W = make_weights(cfg)
+    assert {r[0] for r in t5_rules(cfg) + extra_rules(cfg)} == set(W)                     # every tensor of the blob has a rule
+    path = str(tmp_path / "plus.ckpt")
+    to_checkpoint(W, cfg, path)
+    back = from_checkpoint(path, cfg)
+    assert back.keys() == W.keys() and all(torch.equal(back[k], W[k]) for k in W)
+    cfg8 = cfg.with_(moe_fp8=1)
+    W8, back8 = make_weights(cfg8), from_checkpoint(path, cfg8)
+    assert back8.keys() == W8.keys() and all(torch.equal(back8[k], W8[k]) for k in W8)
+    st = str(tmp_path / "plus.safetensors")
+    to_checkpoint(W, cfg, st)
+    assert all(torch.equal(v, W[k]) for k, v in from_checkpoint(st, cfg).items())
+    sd = torch.load(path, weights_only=True)["state_dict"]
+    del sd["model.ymt3.dec.2.router"]
+    torch.save({"state_dict": sd}, str(tmp_path / "short.ckpt"))
+    with pytest.raises(ValueError, match="dec.2.router"):
+        from_checkpoint(str(tmp_path / "short.ckpt"), cfg)

@@ -3,7 +3,7 @@
 // Used for rocprofv3 --pmc passes (the profiler's counter mode crashes under the torch-bundled
 // HSA runtime) and as the reference for a non-Python binding.
 //   hipcc -O2 tools/ymt3_run.cpp -Iinclude -Lyourmt3_amd -lymt3_hip -Wl,-rpath,$PWD/yourmt3_amd -o tools/ymt3_run
-//   tools/ymt3_run blob.bin [B=64] [L=1024] [passes=1] [step0=0]
+//   tools/ymt3_run blob.bin [B=64] [L=1024] [passes=1] [step0=0] [config=1]      (config 2: the Perceiver-TF encoder of BASELINE configs[2])
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -18,7 +18,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s blob.bin [B] [L] [passes]\n", argv[0]); return 2; }
-    const int B = argc > 2 ? atoi(argv[2]) : 64, L = argc > 3 ? atoi(argv[3]) : 1024, passes = argc > 4 ? atoi(argv[4]) : 1, step0 = argc > 5 ? atoi(argv[5]) : 0;
+    const int B = argc > 2 ? atoi(argv[2]) : 64, L = argc > 3 ? atoi(argv[3]) : 1024, passes = argc > 4 ? atoi(argv[4]) : 1, step0 = argc > 5 ? atoi(argv[5]) : 0, config = argc > 6 ? atoi(argv[6]) : 1;
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     fseek(f, 0, SEEK_END);
@@ -35,6 +35,7 @@ int main(int argc, char** argv) {
     cfg.vocab = 1536; cfg.rel_buckets = 32; cfg.rel_max_distance = 128; cfg.ln_eps = 1e-6f;
     cfg.max_decode_len = 1024; cfg.n_channels = 1; cfg.eos_id = -1; cfg.pad_id = 0;
     cfg.encoder_type = YMT3_ENC_T5; cfg.n_latents = 32; cfg.ptf_d = 128; cfg.ptf_blocks = 3; cfg.ptf_dff = 512; cfg.dec_ffn = YMT3_FFN_DENSE; cfg.n_experts = 8; cfg.moe_top_k = 2;
+    if (config == 2) { cfg.encoder_type = YMT3_ENC_PERCEIVER_TF; cfg.n_enc_layers = 0; }
     cfg.max_batch = B;
 
     ymt3_handle h = nullptr;

@@ -8,56 +8,132 @@ mapped; the audio front-end projection (`in_proj`) has no T5 counterpart and is 
 """
 from __future__ import annotations
 
-from typing import Dict, Mapping, Optional, Tuple
+import functools
+from typing import Dict, List, Mapping, Optional, Tuple
 
 import torch
 
-from .config import YMT3Config
+from .config import YMT3Config, FFN_MOE
 
 
 def _bf16(t: torch.Tensor) -> torch.Tensor:
     return t.detach().float().to(torch.bfloat16).float()
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# The mapping as a TABLE: one rule per tensor of this build, (destination name, source names, kind).  kind: "f32" keeps fp32 (norm gains,
+# biases, relative-position tables), "bf16" rounds a matrix to the blob's storage type, several sources are concatenated along dim 0
+# (q | k | v, k | v) before that.  `t5_rules` states the HF T5 names; `extra_rules` covers every tensor HF T5 has no name for -- the mel
+# projection, the Perceiver-TF encoder, the channel embedding, the MoE router and experts.  Upstream's names for those are unknown
+# (/root/reference holds no code), so their default source is this build's own name under "ymt3." -- what `to_checkpoint` writes -- and a
+# real checkpoint supplies `name_map = {destination: source or [sources]}` instead.
+Rule = Tuple[str, Tuple[str, ...], str]
+
+
+def t5_rules(cfg: YMT3Config) -> List[Rule]:
+    R: List[Rule] = []
+    for l in range(cfg.n_enc_layers):
+        h, p = f"encoder.block.{l}.layer.", f"enc.{l}."
+        R += [(p + "ln1", (h + "0.layer_norm.weight",), "f32"),
+              (p + "wqkv", tuple(h + f"0.SelfAttention.{n}.weight" for n in "qkv"), "bf16"),
+              (p + "wo", (h + "0.SelfAttention.o.weight",), "bf16"),
+              (p + "ln2", (h + "1.layer_norm.weight",), "f32"),
+              (p + "wi", (h + "1.DenseReluDense.wi.weight",), "bf16"),
+              (p + "wo2", (h + "1.DenseReluDense.wo.weight",), "bf16")]
+    if cfg.n_enc_layers:
+        R.append(("enc.relbias", ("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",), "f32"))
+    R.append(("enc.ln_f", ("encoder.final_layer_norm.weight",), "f32"))
+    R.append(("dec.embed", ("decoder.embed_tokens.weight|shared.weight",), "bf16"))          # a|b: the first name present
+    for l in range(cfg.n_dec_layers):
+        h, p = f"decoder.block.{l}.layer.", f"dec.{l}."
+        R += [(p + "ln1", (h + "0.layer_norm.weight",), "f32"),
+              (p + "wqkv", tuple(h + f"0.SelfAttention.{n}.weight" for n in "qkv"), "bf16"),
+              (p + "wo", (h + "0.SelfAttention.o.weight",), "bf16"),
+              (p + "ln2", (h + "1.layer_norm.weight",), "f32"),
+              (p + "wq_c", (h + "1.EncDecAttention.q.weight",), "bf16"),
+              (p + "wkv_c", (h + "1.EncDecAttention.k.weight", h + "1.EncDecAttention.v.weight"), "bf16"),
+              (p + "wo_c", (h + "1.EncDecAttention.o.weight",), "bf16"),
+              (p + "ln3", (h + "2.layer_norm.weight",), "f32")]
+        if cfg.dec_ffn != FFN_MOE:
+            R += [(p + "wi", (h + "2.DenseReluDense.wi.weight",), "bf16"), (p + "wo2", (h + "2.DenseReluDense.wo.weight",), "bf16")]
+    R += [("dec.relbias", ("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",), "f32"),
+          ("dec.ln_f", ("decoder.final_layer_norm.weight",), "f32"),
+          ("dec.lm_head", ("lm_head.weight",), "bf16")]
+    return R
+
+
+_F32_TAILS = ("ln1", "ln2", "ln3", "ln_q", "ln_ff", "ln_x", "ln_out", "ln_f", "relbias", "spec_w", "in_proj.b", "wi_s", "wo2_s")
+
+
+def extra_rules(cfg: YMT3Config) -> List[Rule]:
+    """Every tensor `make_weights(cfg)` has and `t5_rules(cfg)` does not: identity rules under the "ymt3." namespace.  The fp8 expert forms
+    (wi_q8 / wi_s ...) are not stored: the bf16 expert matrices are, and the importer quantises them (weights.quantize_fp8_per_expert)."""
+    have = {r[0] for r in t5_rules(cfg)}
+    R: List[Rule] = []
+    for name in tensor_names(cfg):
+        if name in have or name.endswith(("_q8", "_s")):
+            continue
+        R.append((name, ("ymt3." + name,), "f32" if name.endswith(_F32_TAILS) else "bf16"))
+    if cfg.dec_ffn == FFN_MOE and getattr(cfg, "moe_fp8", 0):
+        for l in range(cfg.n_dec_layers):
+            R += [(f"dec.{l}.wi", (f"ymt3.dec.{l}.wi",), "bf16"), (f"dec.{l}.wo2", (f"ymt3.dec.{l}.wo2",), "bf16")]
+    return R
+
+
+@functools.lru_cache(maxsize=16)
+def tensor_names(cfg: YMT3Config) -> Tuple[str, ...]:
+    """The tensors a blob of this config must hold (the keys of weights.make_weights)."""
+    from .weights import make_weights
+    return tuple(make_weights(cfg, seed=0).keys())
+
+
+def apply_rules(sd: Mapping[str, torch.Tensor], rules: List[Rule], name_map: Optional[Mapping[str, object]] = None) -> Dict[str, torch.Tensor]:
+    W: Dict[str, torch.Tensor] = {}
+    missing = []
+    for dst, srcs, kind in rules:
+        if name_map and dst in name_map:
+            m = name_map[dst]
+            srcs = (m,) if isinstance(m, str) else tuple(m)
+        parts = []
+        for src in srcs:
+            hit = next((a for a in src.split("|") if a in sd), None)
+            if hit is None:
+                missing.append(f"{dst} <- {src}")
+                break
+            parts.append(sd[hit].detach())
+        else:
+            t = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+            W[dst] = t.float() if kind == "f32" else _bf16(t)
+    if missing:
+        raise ValueError("the checkpoint lacks tensors the config needs (destination <- source): " + "; ".join(missing[:12]) +
+                         (f" ... and {len(missing) - 12} more" if len(missing) > 12 else ""))
+    return W
+
+
+def _finish(W: Dict[str, torch.Tensor], cfg: YMT3Config) -> Dict[str, torch.Tensor]:
+    if cfg.dec_ffn == FFN_MOE and getattr(cfg, "moe_fp8", 0):
+        from .weights import quantize_fp8_per_expert
+        for l in range(cfg.n_dec_layers):
+            p = f"dec.{l}."
+            W[p + "wi_q8"], W[p + "wi_s"] = quantize_fp8_per_expert(W.pop(p + "wi"), cfg.n_experts)
+            W[p + "wo2_q8"], W[p + "wo2_s"] = quantize_fp8_per_expert(W.pop(p + "wo2"), cfg.n_experts)
+    for name, t in W.items():
+        if t.is_floating_point() and not torch.isfinite(t).all():
+            raise ValueError(f"non-finite values in imported tensor {name}")
+    _check_shapes(W, cfg)
+    return W
+
+
 def from_t5_state_dict(sd: Mapping[str, torch.Tensor], cfg: YMT3Config, in_proj_w: Optional[torch.Tensor] = None,
                        in_proj_b: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-    """Map HF-T5-named tensors to this build's names; matrices are rounded to bf16 (the blob's storage type)."""
+    """Map HF-T5-named tensors to this build's names (dense T5 encoder / decoder configs); matrices are rounded to bf16 (the blob's storage
+    type).  The mel projection has no T5 name and is passed in (zeros when omitted: only for tests that do not run the front-end)."""
     W: Dict[str, torch.Tensor] = {}
     d = cfg.d_model
     W["in_proj.w"] = _bf16(in_proj_w) if in_proj_w is not None else torch.zeros(d, cfg.n_mels)
     W["in_proj.b"] = in_proj_b.detach().float() if in_proj_b is not None else torch.zeros(d)
-    for l in range(cfg.n_enc_layers):
-        h, p = f"encoder.block.{l}.layer.", f"enc.{l}."
-        W[p + "ln1"] = sd[h + "0.layer_norm.weight"].detach().float()
-        W[p + "wqkv"] = _bf16(torch.cat([sd[h + f"0.SelfAttention.{n}.weight"] for n in "qkv"], 0))
-        W[p + "wo"] = _bf16(sd[h + "0.SelfAttention.o.weight"])
-        W[p + "ln2"] = sd[h + "1.layer_norm.weight"].detach().float()
-        W[p + "wi"] = _bf16(sd[h + "1.DenseReluDense.wi.weight"])
-        W[p + "wo2"] = _bf16(sd[h + "1.DenseReluDense.wo.weight"])
-    W["enc.relbias"] = sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].detach().float()
-    W["enc.ln_f"] = sd["encoder.final_layer_norm.weight"].detach().float()
-    emb = sd.get("decoder.embed_tokens.weight", sd.get("shared.weight"))
-    W["dec.embed"] = _bf16(emb)
-    for l in range(cfg.n_dec_layers):
-        h, p = f"decoder.block.{l}.layer.", f"dec.{l}."
-        W[p + "ln1"] = sd[h + "0.layer_norm.weight"].detach().float()
-        W[p + "wqkv"] = _bf16(torch.cat([sd[h + f"0.SelfAttention.{n}.weight"] for n in "qkv"], 0))
-        W[p + "wo"] = _bf16(sd[h + "0.SelfAttention.o.weight"])
-        W[p + "ln2"] = sd[h + "1.layer_norm.weight"].detach().float()
-        W[p + "wq_c"] = _bf16(sd[h + "1.EncDecAttention.q.weight"])
-        W[p + "wkv_c"] = _bf16(torch.cat([sd[h + "1.EncDecAttention.k.weight"], sd[h + "1.EncDecAttention.v.weight"]], 0))
-        W[p + "wo_c"] = _bf16(sd[h + "1.EncDecAttention.o.weight"])
-        W[p + "ln3"] = sd[h + "2.layer_norm.weight"].detach().float()
-        W[p + "wi"] = _bf16(sd[h + "2.DenseReluDense.wi.weight"])
-        W[p + "wo2"] = _bf16(sd[h + "2.DenseReluDense.wo.weight"])
-    W["dec.relbias"] = sd["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].detach().float()
-    W["dec.ln_f"] = sd["decoder.final_layer_norm.weight"].detach().float()
-    W["dec.lm_head"] = _bf16(sd["lm_head.weight"])
-    for name, t in W.items():
-        if not torch.isfinite(t).all():
-            raise ValueError(f"non-finite values in imported tensor {name}")
-    _check_shapes(W, cfg)
-    return W
+    W.update(apply_rules(sd, t5_rules(cfg)))
+    return _finish(W, cfg)
 
 
 def _check_shapes(W: Dict[str, torch.Tensor], cfg: YMT3Config) -> None:
@@ -65,6 +141,11 @@ def _check_shapes(W: Dict[str, torch.Tensor], cfg: YMT3Config) -> None:
     want = {"dec.embed": (cfg.vocab, d), "dec.lm_head": (cfg.vocab, d), "enc.relbias": (cfg.rel_buckets, cfg.n_heads),
             "dec.relbias": (cfg.rel_buckets, cfg.n_heads), "enc.0.wqkv": (3 * inner, d), "dec.0.wkv_c": (2 * inner, d),
             "enc.0.wi": (cfg.d_ff, d), "dec.0.wo2": (d, cfg.d_ff)}
+    if cfg.n_enc_layers == 0:
+        want.pop("enc.0.wqkv"); want.pop("enc.0.wi"); want.pop("enc.relbias")
+    if cfg.dec_ffn == FFN_MOE:
+        want.pop("dec.0.wo2")
+        want["dec.0.router"] = (cfg.n_experts, d)
     for k, shp in want.items():
         if tuple(W[k].shape) != shp:
             raise ValueError(f"{k}: checkpoint shape {tuple(W[k].shape)} does not match the config {shp}")
@@ -98,14 +179,20 @@ def load_checkpoint_tensors(path: str) -> Dict[str, torch.Tensor]:
     return {k: v for k, v in obj.items() if isinstance(v, torch.Tensor)}
 
 
+_DEC_PROBE = "decoder.block.0.layer.0.SelfAttention.q.weight"
+
+
 def find_t5_prefix(names) -> str:
-    """The module path in front of the T5 stacks, e.g. 'model.' for 'model.encoder.block.0...'."""
-    hits = sorted(n[:-len(_ENC_PROBE)] for n in names if n.endswith(_ENC_PROBE))
-    if not hits:
-        raise ValueError("no T5 encoder found: no tensor name ends with '" + _ENC_PROBE + "'")
-    if len(hits) > 1:
-        raise ValueError(f"several T5 encoders in the checkpoint (prefixes {hits}); pass prefix= explicitly")
-    return hits[0]
+    """The module path in front of the T5 stacks, e.g. 'model.' for 'model.encoder.block.0...' (probed on the T5 encoder's first q
+    projection; on the decoder's where the checkpoint has no T5 encoder -- a Perceiver-TF model)."""
+    names = list(names)
+    for probe in (_ENC_PROBE, _DEC_PROBE):
+        hits = sorted(n[:-len(probe)] for n in names if n.endswith(probe))
+        if len(hits) > 1:
+            raise ValueError(f"several T5 stacks in the checkpoint (prefixes {hits}); pass prefix= explicitly")
+        if hits:
+            return hits[0]
+    raise ValueError("no T5 encoder found: no tensor name ends with '" + _ENC_PROBE + "' (nor a T5 decoder: '" + _DEC_PROBE + "')")
 
 
 def infer_t5_dims(sd: Mapping[str, torch.Tensor]) -> Dict[str, int]:
@@ -119,24 +206,62 @@ def infer_t5_dims(sd: Mapping[str, torch.Tensor]) -> Dict[str, int]:
             "vocab": sd["lm_head.weight"].shape[0]}
 
 
-def from_checkpoint(path: str, cfg: YMT3Config, prefix: Optional[str] = None,
-                    in_proj_names: Optional[Tuple[str, str]] = None) -> Dict[str, torch.Tensor]:
+def from_checkpoint(path: str, cfg: YMT3Config, prefix: Optional[str] = None, in_proj_names: Optional[Tuple[str, str]] = None,
+                    name_map: Optional[Mapping[str, object]] = None, allow_zero_in_proj: bool = False) -> Dict[str, torch.Tensor]:
     """Checkpoint file (Lightning `.ckpt`, bare state dict, safetensors) -> this build's named tensors, ready for `pack_blob`.
 
-    `prefix`: module path in front of `encoder.` / `decoder.` / `lm_head.` (discovered when None).
-    `in_proj_names`: checkpoint names of the mel -> d_model projection's (weight, bias), full names; zeros when None."""
+    `prefix`: module path in front of `encoder.` / `decoder.` / `lm_head.` (discovered when None; source names below are relative to it).
+    `name_map`: {destination: source name or [source names]} overriding the rule table (t5_rules + extra_rules) for any tensor.
+    `in_proj_names`: names of the mel -> d_model projection's (weight, bias) -- shorthand for two `name_map` entries, FULL names.  A T5-encoder
+    config needs that projection: without it (and without `allow_zero_in_proj=True`, for tests that skip the front-end) the import fails,
+    instead of handing back a model whose encoder input is all zeros."""
     raw = load_checkpoint_tensors(path)
     pre = find_t5_prefix(raw) if prefix is None else prefix
     sd = {k[len(pre):]: v for k, v in raw.items() if k.startswith(pre)}
     if "lm_head.weight" not in sd:
         raise ValueError(f"no '{pre}lm_head.weight' in the checkpoint (a tied head is not assumed: export it explicitly)")
-    dims = infer_t5_dims(sd)
-    want = {"d_model": cfg.d_model, "inner": cfg.inner, "n_heads": cfg.n_heads, "rel_buckets": cfg.rel_buckets, "d_ff": cfg.d_ff,
-            "n_enc_layers": cfg.n_enc_layers, "n_dec_layers": cfg.n_dec_layers, "vocab": cfg.vocab}
-    bad = {k: (dims[k], want[k]) for k in want if dims[k] != want[k]}
-    if bad:
-        raise ValueError("checkpoint dims differ from the config (checkpoint, config): " + ", ".join(f"{k} {v}" for k, v in bad.items()))
-    w = b = None
-    if in_proj_names is not None:
-        w, b = raw[in_proj_names[0]], raw[in_proj_names[1]]
-    return from_t5_state_dict(sd, cfg, in_proj_w=w, in_proj_b=b)
+    if cfg.n_enc_layers:
+        dims = infer_t5_dims(sd)
+        want = {"d_model": cfg.d_model, "inner": cfg.inner, "n_heads": cfg.n_heads, "rel_buckets": cfg.rel_buckets, "d_ff": cfg.d_ff,
+                "n_enc_layers": cfg.n_enc_layers, "n_dec_layers": cfg.n_dec_layers, "vocab": cfg.vocab}
+        if cfg.dec_ffn == FFN_MOE:
+            want.pop("d_ff")                         # (read off the encoder's FFN; the MoE decoder's experts are checked by shape below)
+        bad = {k: (dims[k], want[k]) for k in want if dims[k] != want[k]}
+        if bad:
+            raise ValueError("checkpoint dims differ from the config (checkpoint, config): " + ", ".join(f"{k} {v}" for k, v in bad.items()))
+    nm = dict(name_map or {})
+    rules = t5_rules(cfg) + extra_rules(cfg)
+    if "in_proj.w" in {r[0] for r in rules}:
+        if in_proj_names is not None:
+            sd = dict(sd)
+            sd["__in_proj.w"], sd["__in_proj.b"] = raw[in_proj_names[0]], raw[in_proj_names[1]]
+            nm.setdefault("in_proj.w", "__in_proj.w")
+            nm.setdefault("in_proj.b", "__in_proj.b")
+        elif "in_proj.w" not in nm and "ymt3.in_proj.w" not in sd:
+            if not allow_zero_in_proj:
+                raise ValueError("the checkpoint has no mel -> d_model projection under a known name: pass in_proj_names=(weight, bias) "
+                                 "(or allow_zero_in_proj=True to import a model whose encoder input is all zeros)")
+            sd = dict(sd)
+            sd["ymt3.in_proj.w"], sd["ymt3.in_proj.b"] = torch.zeros(cfg.d_model, cfg.n_mels), torch.zeros(cfg.d_model)
+    return _finish(apply_rules(sd, rules, nm), cfg)
+
+
+def to_checkpoint(W: Mapping[str, torch.Tensor], cfg: YMT3Config, path: str, prefix: str = "model.", lightning: bool = True) -> None:
+    """The inverse of the rule table: write this build's tensors as a checkpoint container (`.ckpt`: Lightning-shaped dict with `state_dict`;
+    `.safetensors`: bare) -- HF T5 names for the T5 tensors (concatenated projections split again), "ymt3." names for the others.
+    Lets a YMT3+-shaped set of weights (Perceiver-TF encoder, 13 channels, MoE decoder) round-trip through `from_checkpoint`."""
+    sd: Dict[str, torch.Tensor] = {}
+    W = dict(W)
+    if cfg.dec_ffn == FFN_MOE and getattr(cfg, "moe_fp8", 0):
+        raise ValueError("export the bf16 expert matrices (moe_fp8 = 0 weights); the importer quantises them for an fp8 config")
+    for dst, srcs, _ in t5_rules(cfg) + extra_rules(cfg):
+        t = W[dst].detach().clone()
+        names = [s_.split("|")[0] for s_ in srcs]
+        for n, part in zip(names, t.chunk(len(names), 0) if len(names) > 1 else (t,)):
+            sd[prefix + n] = part.contiguous()
+    if path.endswith(".safetensors"):
+        from safetensors.torch import save_file
+        save_file(sd, path)
+    else:
+        torch.save({"state_dict": sd, "pytorch-lightning_version": "2.1.0", "hyper_parameters": {"note": "written by yourmt3_amd.importer.to_checkpoint"}}
+                   if lightning else sd, path)
