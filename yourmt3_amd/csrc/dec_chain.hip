@@ -79,9 +79,10 @@ bool dec_chain_fits(int n_cus) {
 // 0 = launched; negative = this shape is not the chain's (the caller launches the four GEMMs instead)
 int launch_dec_chain(const ChainArgs& c, hipStream_t stream) {
     if (c.R <= 0) return 0;
-    if (c.R > 64 || c.d_ff != 2048 || c.N3 % 32 || c.N3 / 32 < 32 || c.N3 / 32 > 64 || !c.sync || (c.mode3 != DG_NORM_QKV_CACHE && c.mode3 != DG_NORM_LOGITS))
+    if (c.R > 16 * CHAIN_TILES_MAX || c.d_ff != 2048 || c.N3 % 32 || c.N3 / 32 < 32 || c.N3 / 32 > 64 || !c.sync || (c.mode3 != DG_NORM_QKV_CACHE && c.mode3 != DG_NORM_LOGITS))
         return -1;
-    const int grid = 256;                        // 64 column tiles (stage 1: 2048 / 32) x 4 row-tile slots, one workgroup per CU
+    const int n_mt = (c.R + 15) / 16;
+    const int grid = n_mt <= 4 ? 256 : 64 * n_mt;  // 64 column tiles (stage 1: 2048 / 32) x 4 row-tile slots, one workgroup per CU; beyond 64 rows 64 per row tile
     if (chain_w2f()) {
         if (c.mode3 == DG_NORM_QKV_CACHE)
             dec_chain_kernel<DG_NORM_QKV_CACHE, true><<<grid, 512, CHAIN_LDS_W2F, stream>>>(c.w0, c.w1, c.w2, c.w3, c.attn, c.h, c.row0, c.R, c);

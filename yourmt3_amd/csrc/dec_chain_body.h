@@ -70,7 +70,7 @@ __device__ __forceinline__ void load_w_frag(const bf16_t* W, int n0, u32x4 (&wf)
 // eight (eight lanes, one instruction), a consumer polls the replica of its own XCD slot (8 pollers per line) -- and the poll loop
 // touches nothing else: the clock is read every 64 polls and the abort word only then.
 __device__ __forceinline__ unsigned* chain_counter(unsigned* sync, int boundary, int mt, int replica) {
-    return sync + ((boundary * 4 + mt) * 8 + replica) * CHAIN_LINE;
+    return sync + ((boundary * CHAIN_TILES_MAX + mt) * 8 + replica) * CHAIN_LINE;
 }
 __device__ __forceinline__ void chain_wait(unsigned* sync, int boundary, int mt, unsigned target, unsigned* host_abort, unsigned* abort_at = nullptr) {
     if (YMT3_TID == 0) {
@@ -307,7 +307,11 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
     // in dec_gemm_kernel.  A workgroup without a tile in a stage (row tile beyond R, column tile beyond the stage's N) still requests
     // (and drops) a valid tile's weights: the loads below stay straight-line code, so hipcc's wait counts for stage 0's operands do
     // not fall back to "everything outstanding".
-    const int mt = (t >> 3) & 3, nt = (t >> 5) * 8 + (t & 7);             // nt in [0, 64)
+    // More than four row tiles (65..256 rows): row-tile-major, workgroups 64 mt .. 64 mt + 63 are row tile mt.  Such a grid need NOT be resident
+    // as a whole: a tile's 64 workgroups wait only for each other and are consecutive in dispatch order, so with workgroups dispatched in
+    // index order (per XCD) every row tile below the slowest XCD's dispatch frontier is complete, finishes and frees its slots (observed
+    // order, not a HIP promise: every wait is bounded and runtime.hip recovers through the separate launches).
+    const int mt = n_mt <= 4 ? (t >> 3) & 3 : t >> 6, nt = n_mt <= 4 ? (t >> 5) * 8 + (t & 7) : t & 63;             // nt in [0, 64)
     const int n_nt3 = c.N3 / 32;                                           // 32..64 (launcher)
     const bool has0 = mt < n_mt && nt < 32, has1 = mt < n_mt, has3 = mt < n_mt && nt < n_nt3;
     const int nt0 = nt & 31, mt0 = mt, nt1 = nt, mt1 = mt, nt3 = nt < n_nt3 ? nt : nt - n_nt3, mt3 = mt;

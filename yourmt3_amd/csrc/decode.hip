@@ -1209,7 +1209,7 @@ bool dec_attention_pair_fits(int n_cus) {
 int launch_dec_attention_pair(const DecAttnArgs& a, const DecAttnArgs& b, unsigned* pair_rows, unsigned* abort_word, unsigned* host_abort,
                               hipStream_t stream) {
     if (a.R <= 0) return 0;
-    if (a.R > 64 || a.R != b.R || a.row0 != b.row0 || a.H != 8 || b.H != 8 || !a.wo || !a.opart || !b.wq || b.ipart != a.opart || !pair_rows || !abort_word ||
+    if (a.R > 16 * CHAIN_TILES_MAX || a.R != b.R || a.row0 != b.row0 || a.H != 8 || b.H != 8 || !a.wo || !a.opart || !b.wq || b.ipart != a.opart || !pair_rows || !abort_word ||
         a.rows_per_kv != 1 || b.rows_per_kv < 1 || b.rows_per_kv > 0xff || a.row0 < 0 || a.row0 > 0xffff || a.slab_keys < 1 || a.slab_keys > 0xfffff ||
         b.slab_keys < 1 || b.slab_keys > 0xfffff || b.n_keys_const < 1 || b.n_keys_const > 0xfff || a.bias_stride != a.slab_keys)
         return -1;

@@ -137,14 +137,15 @@ struct ChainArgs {
     const DecodeShared* shared; const int* row_pos;
     int row0, R;
     float eps;
-    unsigned* sync;             // CHAIN_SYNC_WORDS: arrival counters [3 boundaries][4 row tiles][8 replicas], one 128-byte line each (zeroed by the
+    unsigned* sync;             // CHAIN_SYNC_WORDS: arrival counters [3 boundaries][CHAIN_TILES_MAX row tiles][8 replicas], one 128-byte line each (zeroed by the
                                 // preceding cross-attention launch), then the sticky abort word on a line of its own
     unsigned* host_abort;       // pinned host word, set with the abort (the host refuses further calls)
     unsigned long long* stamp;
     unsigned* sync_abort;       // dec_step.hip only: the sticky abort word (the chain launch finds it at sync + CHAIN_ABORT_WORD)
 };
 constexpr int CHAIN_LINE = 32;                                  // 32-bit words per 128-byte line
-constexpr int CHAIN_COUNTERS = 3 * 4 * 8;
+constexpr int CHAIN_TILES_MAX = 16;                             // row tiles of 16 rows a chain launch can hold (256 rows)
+constexpr int CHAIN_COUNTERS = 3 * CHAIN_TILES_MAX * 8;
 constexpr int CHAIN_ABORT_WORD = CHAIN_COUNTERS * CHAIN_LINE;
 constexpr int CHAIN_SYNC_WORDS = (CHAIN_COUNTERS + 1) * CHAIN_LINE;
 int init_chain_kernels();
@@ -176,8 +177,8 @@ struct StepArgs {
     unsigned long long* stamp;                           // measurement (YMT3_STAMP=1) or null: [grid][2] entry / exit clocks, then 16 marks per workgroup from word 1024
     StepLayer layer[8];
 };
-// per layer: the chain's 96 counter lines, then attn_done [4 row tiles][8 replicas], then qkv_done [4 row tiles][8 heads]
-constexpr int STEP_SYNC_LINES_PER_LAYER = 3 * 4 * 8 + 32 + 32;
+// per layer: the chain's counter lines, then attn_done [4 row tiles][8 replicas], then qkv_done [4 row tiles][8 heads]
+constexpr int STEP_SYNC_LINES_PER_LAYER = CHAIN_COUNTERS + 32 + 32;
 constexpr int STEP_SYNC_LINES = 9 * STEP_SYNC_LINES_PER_LAYER;
 int init_step_kernel();
 bool dec_step_fits(int n_cus);

@@ -120,6 +120,7 @@ struct ymt3_ctx {
     bool attn_pair = true;                  // a layer's self- and cross-attention as one launch (decode.hip: dec_attn_pair_kernel; YMT3_NO_ATTN_PAIR=1: two)
     unsigned* pair_rows = nullptr;          // [maxR <= 64][2] counter lines of that kernel (zero between launches)
     bool step_kernel = false;               // a step's six layers as ONE launch (dec_step.hip): YMT3_STEP_KERNEL=1; default: attention pair + GEMM chain per layer
+    int merged_max_rows = 64;               // YMT3_MERGED_MAX_ROWS: the attention pair / GEMM chain are taken up to this many rows (<= 256)
     bool step_tiles_free = false;           // YMT3_STEP_TILES_FREE=1 (A/B): the step kernel's four row tiles as independent pipelines instead of in step
     unsigned* step_sync = nullptr;          // [STEP_SYNC_LINES] counter lines of that kernel (zeroed by the step's argmax kernel / before a decode call)
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
@@ -381,8 +382,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
             HIP_TRY(hipMemset(c->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->chain_host_abort), sizeof(unsigned), hipHostMallocDefault));
             *c->chain_host_abort = 0u;
-            if (dev_alloc(c, (void**)&c->pair_rows, (size_t)64 * 2 * CHAIN_LINE * sizeof(unsigned))) return YMT3_ERR_HIP;
-            HIP_TRY(hipMemset(c->pair_rows, 0, (size_t)64 * 2 * CHAIN_LINE * sizeof(unsigned)));
+            if (dev_alloc(c, (void**)&c->pair_rows, (size_t)16 * CHAIN_TILES_MAX * 2 * CHAIN_LINE * sizeof(unsigned))) return YMT3_ERR_HIP;
+            HIP_TRY(hipMemset(c->pair_rows, 0, (size_t)16 * CHAIN_TILES_MAX * 2 * CHAIN_LINE * sizeof(unsigned)));
         }
     }
     if (k.dec_ffn == YMT3_FFN_MOE) {
@@ -416,6 +417,7 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (const char* mr = getenv("YMT3_DEC_GEMM_MID_ROWS")) c->mid_rows = atoi(mr) < 0 ? -1 : atoi(mr);
     const char* f2 = getenv("YMT3_SELF_ATTN_2WAVE");
     c->force_2wave = f2 && f2[0] == '1';
+    if (const char* mm = getenv("YMT3_MERGED_MAX_ROWS")) { const int v = atoi(mm); if (v >= 16 && v <= 16 * CHAIN_TILES_MAX) c->merged_max_rows = v; }
     { const char* tf = getenv("YMT3_STEP_TILES_FREE"); c->step_tiles_free = tf && tf[0] == '1'; }
     if (const char* ar = getenv("YMT3_ABORT_RECOVERY")) c->abort_recovery = ar[0] == '0' ? 0 : 1;
     const char* nc = getenv("YMT3_CHAINS");
@@ -476,7 +478,7 @@ static int merged_fallback(ymt3_ctx* h) {
     }
     h->step_graphs.clear();
     if (h->chain_sync) HIP_TRY(hipMemset(h->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
-    if (h->pair_rows) HIP_TRY(hipMemset(h->pair_rows, 0, (size_t)64 * 2 * CHAIN_LINE * sizeof(unsigned)));
+    if (h->pair_rows) HIP_TRY(hipMemset(h->pair_rows, 0, (size_t)16 * CHAIN_TILES_MAX * 2 * CHAIN_LINE * sizeof(unsigned)));
     if (h->step_sync) HIP_TRY(hipMemset(h->step_sync, 0, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned)));
     HIP_TRY(hipDeviceSynchronize());
     if (h->chain_host_abort) *h->chain_host_abort = 0u;
@@ -705,10 +707,11 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     // and the per-row fused cross-attention
     // and pays only while the per-(row, head) pull of wo (64 KB each) stays small against the launch it removes: +0.3 % at 64 rows,
     // -1.4 % at 128, -3.5 % at 256 (profiles/r02_b256_fold_fuseq_variants.txt); same bits either way
-    const bool fold = h->fold_o && h->fuse_q && !mc && !h->force_2wave && H == 8 && d == 512 && R <= 96;
+    const bool merged_rows = solo && k.n_channels == 1 && row0 == 0 && R <= h->merged_max_rows && h->attn_pair && h->pair_rows;     // (the pair kernel keeps the fold worthwhile beyond 96 rows)
+    const bool fold = h->fold_o && h->fuse_q && !mc && !h->force_2wave && H == 8 && d == 512 && (R <= 96 || merged_rows);
     // The merged kernels' regime: one channel, up to 64 rows, and this step the only decode stream of the handle (`solo`: with YMT3_CHAINS > 1
     // other row ranges replay on other streams, and the merged kernels need every CU for their own workgroups while they run).
-    const bool merged_regime = fold && solo && k.n_channels == 1 && R <= 64 && row0 == 0;
+    const bool merged_regime = fold && solo && k.n_channels == 1 && R <= h->merged_max_rows && row0 == 0;
     // GEMM chain (dec_chain.hip): after a layer's cross-attention, ONE launch does the cross O-projection, the FFN and the NEXT
     // layer's QKV projection (or lm_head) -- decided per step shape, same bits as the four launches.
     const bool chain = h->gemm_chain && h->chain_sync && merged_regime && k.dec_ffn != YMT3_FFN_MOE && inner == 512 && k.d_ff == 2048 &&
@@ -717,7 +720,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     // O-projection and the fused query projection apply to one channel of up to 64 rows (dense or MoE FFN alike)
     const bool pair_ok = h->attn_pair && h->pair_rows && merged_regime;
     // the per-step kernel (dec_step.hip): layer 0's QKV projection, then ALL layers' attention pairs and GEMM chains as one launch
-    const bool stepk = h->step_kernel && h->step_sync && chain && pair_ok && k.n_dec_layers <= 8 && h->T <= 0xfff;
+    const bool stepk = h->step_kernel && h->step_sync && chain && pair_ok && R <= 64 && k.n_dec_layers <= 8 && h->T <= 0xfff;
     h->step_merged = chain || pair_ok;
     bool qkv_done = false, lm_done = false;         // the previous layer's chain launch already did this layer's QKV / the lm_head
     for (int l = 0; l < k.n_dec_layers; ++l) {
