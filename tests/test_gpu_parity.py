@@ -607,6 +607,40 @@ def test_moe_fp8_expert_gemms_match_oracle(monkeypatch):
     m.close()
 
 
+@pytest.mark.parametrize("fp8", [0, 1], ids=["bf16", "fp8"])
+def test_moe_chain_is_bit_identical_to_the_five_launches(fp8, monkeypatch):
+    """Round 3: an MoE layer's cross O-projection -> router -> expert FFN-in -> expert FFN-out -> next QKV projection (or lm_head, combine folded
+    in) run as ONE launch (moe_chain.hip) whose stages hand row tiles / expert pair sets over through arrival counters and agent-scope
+    loads / stores.  Same arithmetic as the five launches (YMT3_NO_MOE_CHAIN=1), operation for operation: logits and ids must not move by
+    one bit, for one row, ragged and full row tiles, lock-step and slot mode; the router's recorded choices are the same too."""
+    from yourmt3_amd.config import FFN_MOE
+    cfg = YMT3Config(segment_samples=8191, max_decode_len=64, dec_ffn=FFN_MOE, moe_fp8=fp8, eos_id=-1)
+    monkeypatch.setenv("YMT3_DEBUG_HOOKS", "1")
+    monkeypatch.setenv("YMT3_NO_MOE_CHAIN", "1")
+    old = _model(cfg, max_batch=64)
+    monkeypatch.delenv("YMT3_NO_MOE_CHAIN")
+    new = _model(cfg, max_batch=64)
+    monkeypatch.delenv("YMT3_DEBUG_HOOKS")
+    a1 = O.synthetic_audio(2, cfg).cuda()
+    e1 = new.encode(new.logmel(a1))
+    assert new.profile_decode(e1, 8, stride=4)["gemm_chain"]["launches"] == 2 * cfg.n_dec_layers and new.profile_decode(e1, 8, stride=4)["ffn_wi_gemm"]["launches"] == 0
+    assert old.profile_decode(e1, 8, stride=4)["gemm_chain"]["launches"] == 0 and old.profile_decode(e1, 8, stride=4)["ffn_wi_gemm"]["launches"] > 0
+    tr_new, tr_old = new.moe_trace(48), old.moe_trace(48)
+    for B, n in ((1, 48), (5, 48), (21, 32), (40, 24), (64, 48)):
+        a = O.synthetic_audio(B, cfg, seed=40 + B).cuda()
+        e = new.encode(new.logmel(a))
+        t_new, l_new = new.decode(e, n, return_logits=True)
+        t_old, l_old = old.decode(e, n, return_logits=True)
+        assert torch.equal(t_new, t_old) and torch.equal(l_new, l_old), (B, n)
+        assert torch.equal(tr_new[:n, :, :B], tr_old[:n, :, :B]) and int(tr_new[:n, :, :B].min()) >= 0, (B, n)
+        assert int(t_new.min()) >= 0 and torch.equal(new.decode(e, n), t_new)
+    a = O.synthetic_audio(9, cfg, seed=77).cuda()
+    assert torch.equal(new.inference_stream(a, slots=5, interval=4), old.inference_stream(a, slots=5, interval=4))
+    assert torch.equal(new.inference_stream(a, slots=9, interval=8), old.inference(a))
+    new.close()
+    old.close()
+
+
 def _full_size_properties(cfg, B, seed, probe, probe_len=1):
     """Size-independent properties of one BASELINE config at its full size (far beyond what the CPU oracle checks in
     seconds): shape / id range, bitwise reproducibility, independence of a segment from the rest of the batch,

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libymt3_hip.so")
-SOURCES = ["runtime.hip", "frontend.hip", "gemm.hip", "norm.hip", "enc_attn.hip", "decode.hip", "dec_chain.hip", "dec_step.hip", "moe.hip", "mc_cross_attn.hip", "ingest.hip"]
+SOURCES = ["runtime.hip", "frontend.hip", "gemm.hip", "norm.hip", "enc_attn.hip", "decode.hip", "dec_chain.hip", "dec_step.hip", "moe.hip", "moe_chain.hip", "mc_cross_attn.hip", "ingest.hip"]
 HEADERS = ["common.h", "kernels.h", "dec_chain_body.h", os.path.join("..", "..", "include", "ymt3.h")]
 # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs with the dispatch (gfx950) instead of through a
 # scalar load at the head of the kernel; the decode-step kernels put their operand pointers there (decode.hip)

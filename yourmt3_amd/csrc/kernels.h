@@ -291,3 +291,25 @@ struct MoeArgs {
 };
 int init_moe_kernels();
 int launch_moe_stage(int stage, const MoeArgs& a, hipStream_t stream);
+
+// The MoE layer's five skinny launches -- cross O-projection, router, expert FFN-in, expert FFN-out, the next QKV projection (or lm_head) with the
+// combine folded in -- as ONE launch (moe_chain.hip); up to 64 rows, one channel, 8 experts, top-2; bf16 or fp8 expert weights.
+struct MoeChainArgs {
+    const bf16_t* wo_c; const void* wi; const void* wo; const bf16_t* w3;     // [512][512]; experts [8][2048][512] / [8][512][2048] (bf16 or e4m3); next wqkv / lm_head
+    const bf16_t* attn; float* h; const float* part; float* ssq; int ssq_stride;   // as ChainArgs
+    const float* gain_r; const bf16_t* router; bf16_t* xn; int* sel; float* gate;  // router: ln3, [8][512]; scratch [R][512], [2R], [2R]
+    const float* wi_s; const float* wo_s;                                         // fp8: per-expert dequantisation scales
+    bf16_t* hidden; float* y;                                                     // [2R][2048], [2R][512] by pair
+    const float* gain3; int mode3, N3;                                            // stage 4: the next layer's ln1 or ln_f; DG_NORM_QKV_CACHE / DG_NORM_LOGITS
+    float* h_out;                                                                 // QKV mode: the other residual buffer (column tile 0 stores h + y0 + y1 there)
+    bf16_t* out_q; bf16_t* kcache; bf16_t* vcache; float* logits; int H, L;
+    const DecodeShared* shared; const int* row_pos;
+    int R, E, fp8;
+    float eps;
+    unsigned* sync; unsigned* host_abort;                                         // the chain's counter block (zeroed by the preceding cross-attention launch) + abort word
+    unsigned long long* stamp;
+    int32_t* sel_trace; int layer, n_layers, trace_rows, trace_steps;             // debug hook ymt3_debug_moe_trace, as MoeArgs
+};
+int init_moe_chain_kernels();
+bool moe_chain_fits(int n_cus, bool fp8);
+int launch_moe_chain(const MoeChainArgs& c, hipStream_t stream);       // 0 launched, < 0: not this kernel's shape

@@ -120,6 +120,7 @@ struct ymt3_ctx {
     bool attn_pair = true;                  // a layer's self- and cross-attention as one launch (decode.hip: dec_attn_pair_kernel; YMT3_NO_ATTN_PAIR=1: two)
     unsigned* pair_rows = nullptr;          // [maxR <= 64][2] counter lines of that kernel (zero between launches)
     bool step_kernel = false;               // a step's six layers as ONE launch (dec_step.hip): YMT3_STEP_KERNEL=1; default: attention pair + GEMM chain per layer
+    bool moe_chain = false;                 // MoE decoder: a layer's five skinny launches as one (moe_chain.hip; YMT3_NO_MOE_CHAIN=1: separate launches)
     int merged_max_rows = 64;               // YMT3_MERGED_MAX_ROWS: the attention pair / GEMM chain are taken up to this many rows (<= 256)
     bool step_tiles_free = false;           // YMT3_STEP_TILES_FREE=1 (A/B): the step kernel's four row tiles as independent pipelines instead of in step
     unsigned* step_sync = nullptr;          // [STEP_SYNC_LINES] counter lines of that kernel (zeroed by the step's argmax kernel / before a decode call)
@@ -373,11 +374,13 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
         // (YMT3_STEP_KERNEL=1), bit-identical and tested, not the default
         c->step_kernel = c->gemm_chain && c->attn_pair && env1("YMT3_STEP_KERNEL") && !env1("YMT3_TEST_STEP_UNFIT") && init_step_kernel() == 0 &&
                          dec_step_fits(prop.multiProcessorCount);
+        c->moe_chain = k.dec_ffn == YMT3_FFN_MOE && k.n_experts == 8 && c->attn_pair && !env1("YMT3_NO_MOE_CHAIN") && !env1("YMT3_NO_GEMM_CHAIN") &&
+                       !env1("YMT3_TEST_CHAIN_UNFIT") && init_moe_chain_kernels() == 0 && moe_chain_fits(prop.multiProcessorCount, k.moe_fp8 != 0);
         if (c->step_kernel) {
             if (dev_alloc(c, (void**)&c->step_sync, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned))) return YMT3_ERR_HIP;
             HIP_TRY(hipMemset(c->step_sync, 0, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned)));
         }
-        if (c->gemm_chain || c->attn_pair) {
+        if (c->gemm_chain || c->attn_pair || c->moe_chain) {
             if (dev_alloc(c, (void**)&c->chain_sync, CHAIN_SYNC_WORDS * sizeof(unsigned))) return YMT3_ERR_HIP;
             HIP_TRY(hipMemset(c->chain_sync, 0, CHAIN_SYNC_WORDS * sizeof(unsigned)));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->chain_host_abort), sizeof(unsigned), hipHostMallocDefault));
@@ -469,7 +472,7 @@ extern "C" int ymt3_create(const ymt3_config* cfg, const void* blob, size_t nbyt
 // nothing of this handle is still running.  Counters, abort words and the cached step graphs (they hold merged launches) are reset; the
 // separate launches compute the same bits, so the handle goes on working.
 static int merged_fallback(ymt3_ctx* h) {
-    h->gemm_chain = h->attn_pair = h->step_kernel = false;
+    h->gemm_chain = h->attn_pair = h->step_kernel = h->moe_chain = false;
     ++h->fallback_count;
     h->forced_abort = false;
     for (auto& kv : h->step_graphs) {
@@ -720,8 +723,11 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     // O-projection and the fused query projection apply to one channel of up to 64 rows (dense or MoE FFN alike)
     const bool pair_ok = h->attn_pair && h->pair_rows && merged_regime;
     // the per-step kernel (dec_step.hip): layer 0's QKV projection, then ALL layers' attention pairs and GEMM chains as one launch
+    // MoE chain (moe_chain.hip): cross O-projection -> router -> expert FFN-in -> expert FFN-out -> the next QKV projection / lm_head as one launch
+    const bool moe_chain = h->moe_chain && h->chain_sync && pair_ok && fold_combine && k.dec_ffn == YMT3_FFN_MOE && k.n_experts == 8 && inner == 512 && k.d_ff == 2048 &&
+                           k.vocab % 32 == 0 && k.vocab / 32 >= 32 && k.vocab / 32 <= 64 && h->h_dec2;
     const bool stepk = h->step_kernel && h->step_sync && chain && pair_ok && R <= 64 && k.n_dec_layers <= 8 && h->T <= 0xfff;
-    h->step_merged = chain || pair_ok;
+    h->step_merged = chain || pair_ok || moe_chain;
     bool qkv_done = false, lm_done = false;         // the previous layer's chain launch already did this layer's QKV / the lm_head
     for (int l = 0; l < k.n_dec_layers; ++l) {
         const LayerW& W = LW[l];
@@ -804,7 +810,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             PLAUNCH(PC_CROSS_Q, launch_dec_gemm(DG_NORM_BF16, a, s));
         }
         if (pair) {
-            if (chain) t.chain_sync = h->chain_sync;
+            if (chain || moe_chain) t.chain_sync = h->chain_sync;
             ts.stamp = t.stamp = next_stamp(h, PC_ATTN_PAIR, R * H);
             PLAUNCH(PC_ATTN_PAIR, launch_dec_attention_pair(ts, t, h->pair_rows, h->chain_sync + CHAIN_ABORT_WORD, h->chain_host_abort, s));
         } else if (!mc) {
@@ -828,6 +834,30 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             cg.stamp = next_stamp(h, PC_CHAIN, 256);
             PLAUNCH(PC_CHAIN, launch_dec_chain(cg, s));
             if (last) lm_done = true; else qkv_done = true;
+            continue;
+        }
+        if (moe_chain) {
+            const bool last = l + 1 == k.n_dec_layers;
+            MoeChainArgs mc2{};
+            mc2.wo_c = W.wo_c; mc2.w3 = last ? lm_head : LW[l + 1].wqkv;
+            if (k.moe_fp8) { mc2.wi = W.wi_q8; mc2.wo = W.wo_q8; mc2.wi_s = W.wi_s; mc2.wo_s = W.wo_s; }
+            else { mc2.wi = W.wi; mc2.wo = W.wo2; }
+            mc2.attn = h->dattn; mc2.h = hcur; mc2.part = h->opart; mc2.ssq = h->ssq; mc2.ssq_stride = h->maxR;
+            mc2.gain_r = W.ln3; mc2.router = W.router; mc2.xn = h->moe.xn; mc2.sel = h->moe.sel; mc2.gate = h->moe.gate; mc2.hidden = h->moe.hidden; mc2.y = h->moe.y;
+            if (last) GET(h, "dec.ln_f", 0u, const_cast<float**>(&mc2.gain3), (size_t)d);
+            else mc2.gain3 = LW[l + 1].ln1;
+            mc2.mode3 = last ? DG_NORM_LOGITS : DG_NORM_QKV_CACHE; mc2.N3 = last ? k.vocab : 3 * inner;
+            mc2.h_out = last ? nullptr : (hcur == h->h_dec ? h->h_dec2 : h->h_dec);
+            mc2.out_q = h->dq; mc2.kcache = h->kcache + (size_t)(l + 1) * layer_cache; mc2.vcache = h->vcache + (size_t)(l + 1) * layer_cache;
+            mc2.logits = h->logits; mc2.H = H; mc2.L = L; mc2.shared = shared; mc2.row_pos = a.row_pos;
+            mc2.R = R; mc2.E = k.n_experts; mc2.fp8 = k.moe_fp8; mc2.eps = k.ln_eps;
+            mc2.sync = h->chain_sync; mc2.host_abort = h->chain_host_abort;
+            mc2.sel_trace = h->slot_mode ? nullptr : h->moe_trace; mc2.layer = l; mc2.n_layers = k.n_dec_layers;
+            mc2.trace_rows = h->moe_trace_rows; mc2.trace_steps = h->moe_trace_steps;
+            mc2.stamp = next_stamp(h, PC_CHAIN, 256);
+            PLAUNCH(PC_CHAIN, launch_moe_chain(mc2, s));
+            if (last) lm_done = true;
+            else { qkv_done = true; hcur = mc2.h_out; }
             continue;
         }
         a.a_bf16 = h->dattn; a.W = W.wo_c; a.N = d; a.K = inner;
@@ -1265,7 +1295,7 @@ extern "C" int ymt3_debug_kernel_stamps(ymt3_handle h, int kernel, uint64_t* sta
 extern "C" int ymt3_debug_force_stage_abort(ymt3_handle h) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");
     if (!h->debug_hooks) FAIL(YMT3_ERR_UNSUPPORTED, "debug hooks are accepted only by a handle created with YMT3_DEBUG_HOOKS=1 in the environment");
-    if (!h->chain_sync || !h->chain_host_abort || !(h->gemm_chain || h->attn_pair)) FAIL(YMT3_ERR_UNSUPPORTED, "this handle does not run the merged decode kernels");
+    if (!h->chain_sync || !h->chain_host_abort || !(h->gemm_chain || h->attn_pair || h->moe_chain)) FAIL(YMT3_ERR_UNSUPPORTED, "this handle does not run the merged decode kernels");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     const unsigned one = 1u;
