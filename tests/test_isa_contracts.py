@@ -74,3 +74,45 @@ def test_attention_pair_stays_within_two_workgroups_per_cu(decode_asm):
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", k.group(1)).group(1))
     assert vgpr <= 128 and spill == 0 and scratch == 0, (vgpr, spill, scratch)
     assert lds + 65536 <= 80 * 1024, lds          # static + the 64 KB of wo: two per 160 KB CU
+
+
+@pytest.fixture(scope="module")
+def step_asm(tmp_path_factory):
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    from yourmt3_amd import build as B
+    out = tmp_path_factory.mktemp("isa") / "dec_step.s"
+    flags = [f for f in B.FLAGS if f not in ("-fPIC",)]
+    cmd = [hipcc] + flags + ["-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "yourmt3_amd", "csrc", "dec_step.hip"),
+                             "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    return out.read_text()
+
+
+def test_step_kernel_keeps_the_counted_wait_and_fits_two_per_cu(step_asm):
+    """dec_step_kernel (the option YMT3_STEP_KERNEL=1) carries the attention pair's hand-off inside a loop over the layers: the four agent-scope
+    partial stores, then EXACTLY ten loads, then `s_waitcnt vmcnt(10)`, then the row's arrival -- with no drain of the store queue in between
+    (hipcc inserted one when the self-attention half had two instantiations) and no flat-address-space access (its argument struct is re-read
+    from the kernel-argument segment per layer; without the address-space round trip every access becomes a flat one).  512 workgroups must be
+    resident: <= 128 VGPRs, no scratch, 76 KB of LDS."""
+    body = _kernel_body(step_asm, "dec_step_kernel")
+    stores = [i for i, l in enumerate(body) if l.startswith("buffer_store_dwordx4") and " sc1" in l]
+    waits = [i for i, l in enumerate(body) if l.startswith("s_waitcnt vmcnt(10)")]
+    groups = [w for w in waits if any(st < w and w - st < 80 for st in stores)]
+    assert groups, "the hand-off waits with vmcnt(10) right behind the partial stores"
+    w = groups[0]
+    last_store = max(st for st in stores if st < w)
+    four = [l for l in body[last_store - 3:last_store + 1] if l.startswith("buffer_store_dwordx4") and " sc1" in l]
+    assert len(four) == 4, body[last_store - 5:last_store + 1]
+    between = [l for l in body[last_store + 1:w] if VMEM.match(l) or l.startswith("s_waitcnt vmcnt")]
+    assert len(between) == 10 and all(l.startswith("global_load") for l in between), between
+    after = [l for l in body[w + 1:] if VMEM.match(l)]
+    assert after[0].startswith("global_atomic_add"), after[:3]
+    assert not any(l.startswith("flat_load") or l.startswith("flat_atomic") for l in body)
+    m = re.search(r"\.name:\s+\S*dec_step_kernel\S*\n(.*?)\.wavefront_size", step_asm, re.S)
+    meta = m.group(1)
+    vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+    spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
+    assert vgpr <= 128 and spill == 0 and scratch == 0, (vgpr, spill, scratch)
