@@ -253,6 +253,7 @@ struct ArgmaxArgs {
     int* row_pos;               // [R]
     const long long* row_out;   // [R]
     unsigned long long* stamp;  // measurement: as DecGemmArgs::stamp
+    unsigned* ticket;           // or null: [rows / 32 + 1] sub-counters, one 128-byte line each (zero between launches): a two-level ticket for many rows
     unsigned* zero_sync;        // or null: counter lines (CHAIN_LINE words each) to leave zeroed for the next step's dec_step_kernel
     int zero_lines;
 };

@@ -141,165 +141,170 @@ __device__ __forceinline__ void gather_rows(const MoeChainArgs& c, const int* pl
 }
 
 // LDS map of the kernel (bytes from the start of the dynamic block)
-constexpr int L_RED = 0;                                   // [8][16][64] floats (stage 2: 64 columns) + 16 scales
-constexpr int L_WPART = (8 * 16 * 64 + 16) * 4;            // [8][16] floats (stage 4's sum(x^2) per wave)
-constexpr int L_FP8 = L_WPART + 8 * 16 * 4;                // smax[16] (uint), sinv[16], sxs[16]
-constexpr int L_PLIST = L_FP8 + 48 * 4;                    // plist A [128], plist B [128], wcnt [8]
-constexpr int L_STRIPS = L_PLIST + (256 + 16) * 4;
-constexpr int L_STRIPS_ALIGNED = (L_STRIPS + 15) / 16 * 16;
+constexpr int L_PLIST = 0;                                 // the expert's pair list [128] + wcnt [8]
+constexpr int L_FP8 = 576;                                 // smax [32] (uint), sinv [32], sxs [32]: per-row fp8 scales of a pass of <= 32 pairs
+constexpr int L_WPART = L_FP8 + 96 * 4;                    // [8][16] floats (stage 4's sum(x^2) per wave)
+constexpr int L_RED = L_WPART + 8 * 16 * 4;                // cross-wave reduction: [8][16][64] floats in stage 2, [8][16][32] + 16 scales in stage 4, [8][16][16] elsewhere
+constexpr int L_STRIPS = L_RED + (8 * 16 * 64 + 16) * 4;   // operand strips of stages 0, 1 (router rows), 2 and 4
+constexpr int L_STRIPS3 = L_RED + (8 * 16 * 16 + 16) * 4;  // stage 3 (K = 2048, 16 columns) needs 8 KB of reduction space: its 32-row strips start here
+static_assert(L_RED % 16 == 0 && L_STRIPS % 16 == 0 && L_STRIPS3 % 16 == 0, "16-byte LDS accesses");
+constexpr int L_STRIPS_ALIGNED = L_STRIPS;
 
-// stages 2 / 3 on bf16 weights: moe_gemm_kernel<STAGE, K> for the chunks of one expert.  STAGE 0: NT = 4 (64 hidden columns), weights parked in
-// LDS strips; STAGE 1: NT = 1, weight fragments in registers (load_w_frag).  Activation rows gathered by pair at agent scope.
-template <int STAGE>
-__device__ __forceinline__ void expert_chunks_bf16(const MoeChainArgs& c, int R, const int* plist, int cnt_all, int col0, const u32x4* wreg, char* smem, const u32x4* first) {
+// Stages 2 / 3 for ONE expert: moe_gemm_kernel<STAGE> / moe_gemm_fp8_kernel<STAGE> (moe.hip) for its pairs, in ascending pair order, with the
+// same K-slices per wave, MFMA chains per output, reduction order and epilogues -- but up to 32 pairs per pass: both 16-row halves are gathered
+// (and, fp8, quantised) together and share the weight fragments and the barriers; each half's outputs are what a 16-pair chunk of the launch form
+// computes, bit for bit.  (128 pairs over 8 experts: an expert has more than 16 in almost every step, and the second chunk of the slowest expert sat
+// on the chain's critical path: profiles/r03_moe_chain_marks_first.txt.)
+// STAGE 0: hidden[p] = R(relu(xn[row(p)] . wi[e]^T)), 64 columns (NT = 4), K = 512;  STAGE 1: y[p] = gate[p] * (hidden[p] . wo[e]^T), 16 columns, K = 2048.
+// Weights: parked in LDS strips from `wreg`, except bf16 stage 3 (MFMA fragments in registers, load_w_frag).
+template <int STAGE, bool FP8>
+__device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* plist, int cnt_all, int col0, const u32x4* wreg, float wscale, char* smem) {
     constexpr int K = STAGE == 0 ? 512 : 2048, NT = STAGE == 0 ? 4 : 1;
-    using G = Geo<K, NT>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* red = reinterpret_cast<float*>(smem + L_RED);
-    char* strips = smem + L_STRIPS_ALIGNED;
-    char* sA = strips + wave * (STAGE == 0 ? 1 + NT : 1) * G::STRIP;
-    char* sW = sA + G::STRIP;
-    if constexpr (STAGE == 0) {
-#pragma unroll
-        for (int i = 0; i < G::NIW; ++i)
-            *reinterpret_cast<u32x4*>(sW + (i * G::RPIW + lane / G::LPRW) * G::PITCH + (lane % G::LPRW) * 16) = wreg[i];
-    }
-    for (int c0 = 0; c0 < cnt_all; c0 += 16) {
-        const int cnt = min(16, cnt_all - c0);
-        u32x4 av[G::NIA];
-        if (c0 == 0) {                                          // the caller requested the first chunk's rows before parking the weights
-#pragma unroll
-            for (int i = 0; i < G::NIA; ++i) av[i] = first[i];
-        } else {                                                // (requesting chunk c + 1 under chunk c's MFMAs was measured: 358 vs 353 ms per batch, slower)
-            gather_rows<STAGE>(c, plist, cnt_all, c0, av);
-        }
-        float gt = 0.f;                                         // STAGE 1: the pair's gate, requested with the rows instead of behind the reduction
-        if constexpr (STAGE == 1) {
-            if (tid < 16 * 8 && tid / 8 < cnt) gt = ld_agent(c.gate + plist[c0 + tid / 8]);
-        }
-#pragma unroll
-        for (int i = 0; i < G::NIA; ++i)
-            *reinterpret_cast<u32x4*>(sA + (i * G::RPIW + lane / G::LPRW) * G::PITCH + (lane % G::LPRW) * 16) = av[i];
-        float2 s;
-        if constexpr (STAGE == 0) s = mfma_reduce<K, NT>(sA, sW, red);
-        else {
-            u32x4 wf[G::KS];
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) wf[ks] = wreg[ks];
-            s = mfma_reduce_wfrag<K>(sA, wf, red);
-        }
-        if (tid < 16 * 8 * NT) {
-            const int mr = tid / (8 * NT), nq = (tid % (8 * NT)) * 2;
-            if (mr < cnt) {
-                const int pp = plist[c0 + mr];
-                if constexpr (STAGE == 0) {
-                    st_agent(reinterpret_cast<uint32_t*>(c.hidden + (size_t)pp * 2048 + col0 + nq), pack_bf16x2(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f)));
-                } else {
-                    st2_agent(c.y + (size_t)pp * 512 + col0 + nq, make_float2(gt * s.x, gt * s.y));
-                }
-            }
-        }
-        __syncthreads();                                       // `red` and the activation strips are reused by the next chunk
-    }
-    (void)R;
-}
-
-// the fp8 (OCP e4m3) form: moe_gemm_fp8_kernel<STAGE, K> for the chunks of one expert; weights parked in LDS strips by the caller's registers
-template <int STAGE>
-__device__ __forceinline__ void expert_chunks_fp8(const MoeChainArgs& c, const int* plist, int cnt_all, int col0, int ntile, const u32x4* wreg, float wscale, char* smem,
-                                                  const u32x4* first) {
-    constexpr int K = STAGE == 0 ? 512 : 2048;
-    constexpr int KW = K / 8, KS = KW / 32, PITCH = KW + 16, STRIP = 16 * PITCH;
-    constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;          // bf16 activation rows
-    constexpr int LPRW = KW / 16, RPIW = 64 / LPRW, NIW = 16 / RPIW;         // fp8 weight rows of one 16-column tile
+    constexpr int KW = K / 8, KS = KW / 32;
+    constexpr int PITCH = FP8 ? KW + 16 : KW * 2 + 16, STRIP = 16 * PITCH;
+    constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;                               // a gathered bf16 row slice: lanes per row, rows per instruction
+    constexpr int LPRW = FP8 ? KW / 16 : KW * 2 / 16, RPIW = 64 / LPRW, NIW = 16 * NT / RPIW;     // the weight rows of the tile as loaded (whole lines)
+    constexpr bool WREG = !FP8 && STAGE == 1;
+    constexpr int NSTRIP = 2 + (WREG ? 0 : NT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-    float* red = reinterpret_cast<float*>(smem + L_RED);                      // [8][16][16] per 16-column tile pass
+    float* red = reinterpret_cast<float*>(smem + L_RED);
     unsigned* smax = reinterpret_cast<unsigned*>(smem + L_FP8);
-    float* sinv = reinterpret_cast<float*>(smax + 16);
-    float* sxs = sinv + 16;
-    char* strips = smem + L_STRIPS_ALIGNED;
-    constexpr int NSTRIPS = STAGE == 0 ? 5 : 2;                               // A strip + four weight tiles (stage 2) / one (stage 3)
-    char* sA = strips + wave * NSTRIPS * STRIP;
-    char* sW = sA + STRIP;
-    for (int tt = 0; tt < ntile; ++tt)
+    float* sinv = reinterpret_cast<float*>(smax + 32);
+    float* sxs = sinv + 32;
+    char* sA0 = smem + (STAGE == 0 ? L_STRIPS : L_STRIPS3) + wave * NSTRIP * STRIP;
+    char* sA1 = sA0 + STRIP;
+    char* sW = sA1 + STRIP;
+    if constexpr (!WREG) {
 #pragma unroll
         for (int i = 0; i < NIW; ++i)
-            *reinterpret_cast<u32x4*>(sW + tt * STRIP + (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16) = wreg[tt * NIW + i];
-    for (int c0 = 0; c0 < cnt_all; c0 += 16) {
-        const int cnt = min(16, cnt_all - c0);
-        if (tid < 16) smax[tid] = 0u;
-        __syncthreads();
-        u32x4 av[NI];
-        if (c0 == 0) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) av[i] = first[i];
-        } else {
-            gather_rows<STAGE>(c, plist, cnt_all, c0, av);
-        }
-        float gt = 0.f;
+            *reinterpret_cast<u32x4*>(sW + (i * RPIW + lane / LPRW) * PITCH + (lane % LPRW) * 16) = wreg[i];
+    }
+    const bool epi = tid < 16 * 8 * NT;
+    const int mr = tid / (8 * NT), nq = (tid % (8 * NT)) * 2;
+    for (int c0 = 0; c0 < cnt_all; c0 += 32) {
+        const int cnt = min(32, cnt_all - c0);
+        const bool two = cnt > 16;                              // workgroup-uniform
+        u32x4 a0[NI], a1[NI];
+        gather_rows<STAGE>(c, plist, cnt_all, c0, a0);
+        if (two) gather_rows<STAGE>(c, plist, cnt_all, c0 + 16, a1);
+        float gt0 = 0.f, gt1 = 0.f;                             // STAGE 1: the pairs' gates, requested with the rows instead of behind the reduction
         if constexpr (STAGE == 1) {
-            if (tid < 128 && (tid >> 3) < cnt) gt = ld_agent(c.gate + plist[c0 + (tid >> 3)]);
+            if (epi && mr < cnt) gt0 = ld_agent(c.gate + plist[c0 + mr]);
+            if (epi && 16 + mr < cnt) gt1 = ld_agent(c.gate + plist[c0 + 16 + mr]);
         }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float mx = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] << 16)));
-                mx = fmaxf(mx, fabsf(__uint_as_float(av[i][j] & 0xffff0000u)));
-            }
-            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));
-            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));
-            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x141, 0xF, 0xF, true)));
-            if ((lane & 7) == 0) atomicMax(&smax[i * RPI + lane / LPR], __float_as_uint(mx));
-        }
-        __syncthreads();
-        if (tid < 16) {
-            const float mx = fmaxf(__uint_as_float(smax[tid]), 1e-12f);
-            sinv[tid] = 448.0f / mx;
-            sxs[tid] = mx / 448.0f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int row = i * RPI + lane / LPR;
-            const float inv = sinv[row];
-            int lo = 0, hi = 0;
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][0] << 16) * inv, __uint_as_float(av[i][0] & 0xffff0000u) * inv, lo, false);
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][1] << 16) * inv, __uint_as_float(av[i][1] & 0xffff0000u) * inv, lo, true);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][2] << 16) * inv, __uint_as_float(av[i][2] & 0xffff0000u) * inv, hi, false);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][3] << 16) * inv, __uint_as_float(av[i][3] & 0xffff0000u) * inv, hi, true);
-            *reinterpret_cast<int2*>(sA + row * PITCH + (lane % LPR) * 8) = make_int2(lo, hi);
-        }
-        for (int tt = 0; tt < ntile; ++tt) {                                  // the same quantised rows against each 16-column weight tile
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int o = li * PITCH + ks * 32 + g * 8;
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(*reinterpret_cast<const long*>(sW + tt * STRIP + o), *reinterpret_cast<const long*>(sA + o), acc, 0, 0, 0);
-            }
-            *reinterpret_cast<float4*>(red + ((wave * 16 + li) * 16 + g * 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if constexpr (FP8) {
+            // per-row dynamic scale (amax / 448): 8-lane DPP max, then one LDS integer max per (row, 8-lane group) -- |x| >= 0, so float bit patterns order like unsigned integers
+            if (tid < 32) smax[tid] = 0u;
             __syncthreads();
-            if (tid < 128) {
-                const int mr = tid >> 3, nq = (tid & 7) * 2;
-                float2 s = *reinterpret_cast<const float2*>(red + (mr * 16 + nq));
+            auto row_max = [&](const u32x4 (&av)[NI], int base) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    float mx = 0.f;
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) {
+                        mx = fmaxf(mx, fabsf(__uint_as_float(av[i][jq] << 16)));
+                        mx = fmaxf(mx, fabsf(__uint_as_float(av[i][jq] & 0xffff0000u)));
+                    }
+                    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));
+                    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));
+                    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x141, 0xF, 0xF, true)));
+                    if ((lane & 7) == 0) atomicMax(&smax[base + i * RPI + lane / LPR], __float_as_uint(mx));
+                }
+            };
+            row_max(a0, 0);
+            if (two) row_max(a1, 16);
+            __syncthreads();
+            if (tid < 32) {
+                const float mx = fmaxf(__uint_as_float(smax[tid]), 1e-12f);
+                sinv[tid] = 448.0f / mx;
+                sxs[tid] = mx / 448.0f;
+            }
+            __syncthreads();
+            auto quant = [&](const u32x4 (&av)[NI], int base, char* sA) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int row = i * RPI + lane / LPR;
+                    const float inv = sinv[base + row];
+                    int lo = 0, hi = 0;
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][0] << 16) * inv, __uint_as_float(av[i][0] & 0xffff0000u) * inv, lo, false);
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][1] << 16) * inv, __uint_as_float(av[i][1] & 0xffff0000u) * inv, lo, true);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][2] << 16) * inv, __uint_as_float(av[i][2] & 0xffff0000u) * inv, hi, false);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][3] << 16) * inv, __uint_as_float(av[i][3] & 0xffff0000u) * inv, hi, true);
+                    *reinterpret_cast<int2*>(sA + row * PITCH + (lane % LPR) * 8) = make_int2(lo, hi);
+                }
+            };
+            quant(a0, 0, sA0);
+            if (two) quant(a1, 16, sA1);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int off = (i * RPI + lane / LPR) * PITCH + (lane % LPR) * 16;
+                *reinterpret_cast<u32x4*>(sA0 + off) = a0[i];
+                if (two) *reinterpret_cast<u32x4*>(sA1 + off) = a1[i];
+            }
+        }
+        // MFMA: one chain per (half, 16-column tile) over this wave's K-slice; a weight fragment is read once for both halves
+        f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) { acc0[tt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[tt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (FP8) {
+                const int o = li * PITCH + ks * 32 + g * 8;
+                const long af0 = *reinterpret_cast<const long*>(sA0 + o);
+                const long af1 = two ? *reinterpret_cast<const long*>(sA1 + o) : 0L;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const long wf = *reinterpret_cast<const long*>(sW + tt * STRIP + o);
+                    acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf, af0, acc0[tt], 0, 0, 0);
+                    if (two) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf, af1, acc1[tt], 0, 0, 0);
+                }
+            } else {
+                const int o = li * PITCH + (ks * 32 + g * 8) * 2;
+                const bf16x8 af0 = *reinterpret_cast<const bf16x8*>(sA0 + o);
+                bf16x8 af1 = af0;
+                if (two) af1 = *reinterpret_cast<const bf16x8*>(sA1 + o);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    bf16x8 wf;
+                    if constexpr (WREG) wf = __builtin_bit_cast(bf16x8, wreg[ks]);
+                    else wf = *reinterpret_cast<const bf16x8*>(sW + tt * STRIP + o);
+                    acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af0, acc0[tt], 0, 0, 0);
+                    if (two) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af1, acc1[tt], 0, 0, 0);
+                }
+            }
+        }
+        // fixed-order cross-wave reduction and epilogue, one half after the other (the reduction space holds one)
+        for (int half = 0; half < (two ? 2 : 1); ++half) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const f32x4 a = half ? acc1[tt] : acc0[tt];
+                *reinterpret_cast<float4*>(red + ((wave * 16 + li) * (16 * NT) + tt * 16 + g * 4)) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+            __syncthreads();
+            if (epi) {
+                float2 sv = *reinterpret_cast<const float2*>(red + (mr * (16 * NT) + nq));
 #pragma unroll
                 for (int w = 1; w < 8; ++w) {
-                    const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * 16 + nq));
-                    s.x += t.x; s.y += t.y;
+                    const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * (16 * NT) + nq));
+                    sv.x += t.x; sv.y += t.y;
                 }
-                if (mr < cnt) {
-                    const int pp = plist[c0 + mr];
-                    const float sc = sxs[mr] * wscale;
-                    s.x *= sc; s.y *= sc;
+                const int rr = 16 * half + mr;
+                if (rr < cnt) {
+                    const int pp = plist[c0 + rr];
+                    if constexpr (FP8) {
+                        const float sc = sxs[rr] * wscale;
+                        sv.x *= sc; sv.y *= sc;
+                    }
                     if constexpr (STAGE == 0) {
-                        st_agent(reinterpret_cast<uint32_t*>(c.hidden + (size_t)pp * 2048 + col0 + tt * 16 + nq), pack_bf16x2(fmaxf(s.x, 0.f), fmaxf(s.y, 0.f)));
+                        st_agent(reinterpret_cast<uint32_t*>(c.hidden + (size_t)pp * 2048 + col0 + nq), pack_bf16x2(fmaxf(sv.x, 0.f), fmaxf(sv.y, 0.f)));
                     } else {
-                        st2_agent(c.y + (size_t)pp * 512 + col0 + tt * 16 + nq, make_float2(gt * s.x, gt * s.y));
+                        const float gt = half ? gt1 : gt0;
+                        st2_agent(c.y + (size_t)pp * 512 + col0 + nq, make_float2(gt * sv.x, gt * sv.y));
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads();                                   // the reduction space (and, after the last half, the strips and the scales) are reused
         }
     }
 }
@@ -484,28 +489,20 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     }
     // ---- stage 2: expert FFN-in, 64 hidden columns of expert e2 for its pairs (an expert nobody chose costs a scan)
     int* plist = reinterpret_cast<int*>(smem + L_PLIST);
-    int* wcnt = plist + 256;
+    int* wcnt = plist + 128;
     mc_wait(c.sync, MC_ROUTER, (unsigned)(2 * n_mt), c.host_abort);
     CH_MARK(c, 3);
     const int cnt = find_pairs(c.sel, 2 * R, e2, plist, wcnt);
-    if (cnt) {
-        u32x4 av1[Geo<512, 1>::NIA];
-        gather_rows<0>(c, plist, cnt, 0, av1);
-        if constexpr (FP8) expert_chunks_fp8<0>(c, plist, cnt, ot * 64, 4, wi4, c.wi_s[e2], smem, av1);
-        else expert_chunks_bf16<0>(c, R, plist, cnt, ot * 64, wi4, smem, av1);
-    }
+    float ws_in = 1.f, ws_out = 1.f;
+    if constexpr (FP8) { ws_in = c.wi_s[e2]; ws_out = c.wo_s[e2]; }
+    if (cnt) expert_pass<0, FP8>(c, plist, cnt, ot * 64, wi4, ws_in, smem);
     mc_signal(c.sync, MC_FFN_IN + e2 * 8);
     CH_MARK(c, 4);
     // ---- stage 3: expert FFN-out, 16 output columns of the same expert
     {
         mc_wait(c.sync, MC_FFN_IN + e2 * 8, 32u, c.host_abort);
         CH_MARK(c, 5);
-        if (cnt) {
-            u32x4 av2[Geo<2048, 1>::NIA];
-            gather_rows<1>(c, plist, cnt, 0, av2);
-            if constexpr (FP8) expert_chunks_fp8<1>(c, plist, cnt, ot * 16, 1, wo2, c.wo_s[e2], smem, av2);
-            else expert_chunks_bf16<1>(c, R, plist, cnt, ot * 16, wo2, smem, av2);
-        }
+        if (cnt) expert_pass<1, FP8>(c, plist, cnt, ot * 16, wo2, ws_out, smem);
         mc_signal(c.sync, MC_FFN_OUT);
         CH_MARK(c, 6);
     }
@@ -518,14 +515,13 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     CH_STAMP_OUT(c);
 }
 
-constexpr size_t MOE_CHAIN_LDS_BF16 = (size_t)L_STRIPS_ALIGNED + (size_t)8 * 5 * 16 * (512 / 8 * 2 + 16);              // stage 2: A strip + four weight strips per wave (stage 3: 67.6 KB)
-constexpr size_t MOE_CHAIN_LDS_FP8 = (size_t)L_STRIPS_ALIGNED + (size_t)8 * 2 * 16 * (2048 / 8 + 16);                  // stage 3: A strip + one weight strip per wave (the largest stage)
-static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS_ALIGNED + (size_t)8 * 5 * 16 * (512 / 8 + 16), "stage 2 (fp8): A strip + four weight strips");
-static_assert(MOE_CHAIN_LDS_BF16 >= (size_t)L_STRIPS_ALIGNED + (size_t)8 * 16 * (2048 / 8 * 2 + 16), "stage 3's activation strips (weights in registers)");
+constexpr size_t MOE_CHAIN_LDS_BF16 = (size_t)L_STRIPS3 + (size_t)8 * 2 * 16 * (2048 / 8 * 2 + 16);                 // stage 3: two 16-row activation strips per wave (weights in registers)
+constexpr size_t MOE_CHAIN_LDS_FP8 = (size_t)L_STRIPS3 + (size_t)8 * 3 * 16 * (2048 / 8 + 16);                      // stage 3: two activation strips + the weight strip
+static_assert(MOE_CHAIN_LDS_BF16 >= (size_t)L_STRIPS + (size_t)8 * 6 * 16 * (512 / 8 * 2 + 16), "stage 2 (bf16): two activation + four weight strips per wave");
+static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS + (size_t)8 * 6 * 16 * (512 / 8 + 16), "stage 2 (fp8)");
+static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS + (size_t)8 * 3 * 16 * (512 / 8 * 2 + 16), "stages 0 and 4 (bf16 strips) in the fp8 kernel");
+static_assert(MOE_CHAIN_LDS_BF16 >= (size_t)L_STRIPS + 8 * 512 * 4 && MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS + 8 * 512 * 4, "router rows");
 static_assert(MOE_CHAIN_LDS_BF16 <= 160 * 1024 && MOE_CHAIN_LDS_FP8 <= 160 * 1024, "one workgroup per CU");
-static_assert(MOE_CHAIN_LDS_BF16 >= (size_t)L_STRIPS_ALIGNED + 8 * 3 * 16 * (512 / 8 * 2 + 16), "stages 2 and 4");
-static_assert(MOE_CHAIN_LDS_BF16 >= (size_t)L_STRIPS_ALIGNED + 8 * 512 * 4, "router rows");
-static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS_ALIGNED + 8 * 3 * 16 * (512 / 8 * 2 + 16), "stage 4 (bf16 strips) in the fp8 kernel");
 
 template <int MODE3, bool FP8>
 int set_lds() {

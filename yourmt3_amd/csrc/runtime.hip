@@ -123,6 +123,7 @@ struct ymt3_ctx {
     bool moe_chain = false;                 // MoE decoder: a layer's five skinny launches as one (moe_chain.hip; YMT3_NO_MOE_CHAIN=1: separate launches)
     int merged_max_rows = 64;               // YMT3_MERGED_MAX_ROWS: the attention pair / GEMM chain are taken up to this many rows (<= 256)
     bool step_tiles_free = false;           // YMT3_STEP_TILES_FREE=1 (A/B): the step kernel's four row tiles as independent pipelines instead of in step
+    unsigned* ticket = nullptr;             // [maxR / 32 + 1] lines: the argmax kernel's two-level ticket (many rows)
     unsigned* step_sync = nullptr;          // [STEP_SYNC_LINES] counter lines of that kernel (zeroed by the step's argmax kernel / before a decode call)
     // sampled per-kernel-class timing (ymt3_profile_decode): events bracket single launches
     bool prof_on = false;
@@ -359,6 +360,8 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     if (dev_alloc(c, (void**)&c->row_out, R * 8)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->ssq, (size_t)SSQ_TILES * R * 4)) return YMT3_ERR_HIP;
     if (dev_alloc(c, (void**)&c->opart, R * k.n_heads * d * 4)) return YMT3_ERR_HIP;
+    if (dev_alloc(c, (void**)&c->ticket, (R / 32 + 1) * CHAIN_LINE * sizeof(unsigned))) return YMT3_ERR_HIP;
+    HIP_TRY(hipMemset(c->ticket, 0, (R / 32 + 1) * CHAIN_LINE * sizeof(unsigned)));
     {   // The merged decode kernels (GEMM chain: 256 workgroups of 143 KB LDS; attention pair: 512 of 72 KB) wait for each other inside one
         // launch, so every workgroup of their grids must be resident at once: a kernel is enabled only if the switch allows it AND the
         // runtime's occupancy answer x CUs covers its grid.  YMT3_TEST_CHAIN_UNFIT / YMT3_TEST_PAIR_UNFIT = 1 force "does not fit" for
@@ -901,6 +904,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     GET(h, "dec.embed", 1u, const_cast<bf16_t**>(&g.embed), (size_t)k.vocab * d);
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&g.chan_embed), (size_t)k.n_channels * d);
     if (h->slot_mode) { g.row_pos = h->row_pos; g.row_out = h->row_out; }
+    if (solo) g.ticket = h->ticket;                  // (row ranges of several chains would share groups)
     if (stepk) { g.zero_sync = h->step_sync; g.zero_lines = k.n_dec_layers * STEP_SYNC_LINES_PER_LAYER; }
     g.stamp = next_stamp(h, PC_ARGMAX, R);
     PLAUNCH(PC_ARGMAX, launch_argmax_embed(g, s));
