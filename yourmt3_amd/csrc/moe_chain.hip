@@ -26,11 +26,41 @@ namespace {
 
 #include "dec_chain_body.h"
 
-constexpr int MC_B0 = 0, MC_ROUTER = 32, MC_FFN_IN = 40, MC_FFN_OUT = 104;       // counter lines (x CHAIN_LINE words): [4][8], [8], [8 experts][8], [8]
-static_assert(MC_FFN_OUT + 8 <= CHAIN_COUNTERS, "the MoE chain's counters live in the chain's counter block (zeroed by the preceding cross-attention launch)");
+constexpr int MC_B0 = 0, MC_ROUTER = 32, MC_FFN_IN = 40, MC_FFN_OUT = 104;       // counter lines (x CHAIN_LINE words): [4][8], [8], [8 experts][8], [8 experts][8]
+static_assert(MC_FFN_OUT + 64 <= CHAIN_COUNTERS, "the MoE chain's counters live in the chain's counter block (zeroed by the preceding cross-attention launch)");
 
 __device__ __forceinline__ void mc_wait(unsigned* sync, int line0, unsigned target, unsigned* host_abort) {
     counter_wait(sync + (size_t)(line0 + (blockIdx.x & 7)) * CHAIN_LINE, target, sync + CHAIN_ABORT_WORD, host_abort);
+}
+// wait until EIGHT counters (lines line0 + 8 e + this workgroup's replica, e = 0..7) have all reached `target`: one poll instruction, eight lanes.
+// (Stage 4 needs every expert's outputs.  One counter for all 256 producers made the slowest arrival visible ~2 us late: adds to one line are served
+// one after the other, and the producers finish together -- profiles/r03_moe_chain_marks_parts.txt.)
+__device__ __forceinline__ void mc_wait8(unsigned* sync, int line0, unsigned target, unsigned* host_abort) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned* cnt = sync + (size_t)(line0 + (lane & 7) * 8 + (blockIdx.x & 7)) * CHAIN_LINE;
+        unsigned* abort_word = sync + CHAIN_ABORT_WORD;
+        unsigned long long t0 = 0;
+        unsigned polls = 0;
+        for (;;) {
+            unsigned v = target;
+            if (lane < 8) v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(v < target) == 0ull) break;
+            YMT3_POLL_PAUSE;
+            if ((++polls & 63u) == 0u) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > SPIN_LIMIT) {
+                    if (lane == 0) {
+                        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (host_abort) __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
 }
 __device__ __forceinline__ void mc_signal(unsigned* sync, int line0) { counter_signal(sync + (size_t)line0 * CHAIN_LINE, 8, CHAIN_LINE); }
 
@@ -146,32 +176,34 @@ constexpr int L_FP8 = 576;                                 // smax [32] (uint), 
 constexpr int L_WPART = L_FP8 + 96 * 4;                    // [8][16] floats (stage 4's sum(x^2) per wave)
 constexpr int L_RED = L_WPART + 8 * 16 * 4;                // cross-wave reduction: [8][16][64] floats in stage 2, [8][16][32] + 16 scales in stage 4, [8][16][16] elsewhere
 constexpr int L_STRIPS = L_RED + (8 * 16 * 64 + 16) * 4;   // operand strips of stages 0, 1 (router rows), 2 and 4
-constexpr int L_STRIPS3 = L_RED + (8 * 16 * 16 + 16) * 4;  // stage 3 (K = 2048, 16 columns) needs 8 KB of reduction space: its 32-row strips start here
-static_assert(L_RED % 16 == 0 && L_STRIPS % 16 == 0 && L_STRIPS3 % 16 == 0, "16-byte LDS accesses");
+constexpr int l_strips3(int nt) { return L_RED + (8 * 16 * 16 * nt + 16) * 4; }   // stage 3 (K = 2048, 16 nt columns): its 32-row strips start behind 8 nt KB of reduction space
+static_assert(L_RED % 16 == 0 && L_STRIPS % 16 == 0 && l_strips3(2) % 16 == 0 && l_strips3(4) % 16 == 0, "16-byte LDS accesses");
 constexpr int L_STRIPS_ALIGNED = L_STRIPS;
 
-// Stages 2 / 3 for ONE expert: moe_gemm_kernel<STAGE> / moe_gemm_fp8_kernel<STAGE> (moe.hip) for its pairs, in ascending pair order, with the
-// same K-slices per wave, MFMA chains per output, reduction order and epilogues -- but up to 32 pairs per pass: both 16-row halves are gathered
-// (and, fp8, quantised) together and share the weight fragments and the barriers; each half's outputs are what a 16-pair chunk of the launch form
-// computes, bit for bit.  (128 pairs over 8 experts: an expert has more than 16 in almost every step, and the second chunk of the slowest expert sat
-// on the chain's critical path: profiles/r03_moe_chain_marks_first.txt.)
-// STAGE 0: hidden[p] = R(relu(xn[row(p)] . wi[e]^T)), 64 columns (NT = 4), K = 512;  STAGE 1: y[p] = gate[p] * (hidden[p] . wo[e]^T), 16 columns, K = 2048.
-// Weights: parked in LDS strips from `wreg`, except bf16 stage 3 (MFMA fragments in registers, load_w_frag).
-template <int STAGE, bool FP8>
-__device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* plist, int cnt_all, int col0, const u32x4* wreg, float wscale, char* smem) {
-    constexpr int K = STAGE == 0 ? 512 : 2048, NT = STAGE == 0 ? 4 : 1;
+// Stages 2 / 3 for ONE expert: moe_gemm_kernel<STAGE> / moe_gemm_fp8_kernel<STAGE> (moe.hip) for `cnt_all` of its pairs, in ascending pair order,
+// with the same K-slices per wave, MFMA chains per output, reduction order and epilogues -- but up to 32 pairs per pass: both 16-row halves are
+// gathered (and, fp8, quantised) together and share the weight fragments and the barriers; each half's outputs are what a 16-pair chunk of the
+// launch form computes, bit for bit.  (128 pairs over 8 experts: an expert has more than 16 in almost every step, and the second chunk of the
+// slowest expert sat on the chain's critical path: profiles/r03_moe_chain_marks_first.txt.)
+// STAGE 0: hidden[p] = R(relu(xn[row(p)] . wi[e]^T)), 64 columns (NT = 4), K = 512, weights parked in LDS strips from `wreg` (row layout);
+// STAGE 1: y[p] = gate[p] * (hidden[p] . wo[e]^T), 16 NT columns, K = 2048, weights as MFMA fragments in registers: wreg[tt * KS + ks] (bf16, 16 B)
+//          or wreg8[tt * KS + ks] (fp8, 8 B).
+template <int STAGE, bool FP8, int NT>
+__device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* plist, int cnt_all, int col0, const u32x4* wreg, const long* wreg8, float wscale, char* smem) {
+    constexpr int K = STAGE == 0 ? 512 : 2048;
+    static_assert(STAGE == 1 || NT == 4, "stage 2 takes 64 hidden columns");
     constexpr int KW = K / 8, KS = KW / 32;
     constexpr int PITCH = FP8 ? KW + 16 : KW * 2 + 16, STRIP = 16 * PITCH;
     constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;                               // a gathered bf16 row slice: lanes per row, rows per instruction
     constexpr int LPRW = FP8 ? KW / 16 : KW * 2 / 16, RPIW = 64 / LPRW, NIW = 16 * NT / RPIW;     // the weight rows of the tile as loaded (whole lines)
-    constexpr bool WREG = !FP8 && STAGE == 1;
+    constexpr bool WREG = STAGE == 1;
     constexpr int NSTRIP = 2 + (WREG ? 0 : NT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     float* red = reinterpret_cast<float*>(smem + L_RED);
     unsigned* smax = reinterpret_cast<unsigned*>(smem + L_FP8);
     float* sinv = reinterpret_cast<float*>(smax + 32);
     float* sxs = sinv + 32;
-    char* sA0 = smem + (STAGE == 0 ? L_STRIPS : L_STRIPS3) + wave * NSTRIP * STRIP;
+    char* sA0 = smem + (STAGE == 0 ? L_STRIPS : l_strips3(NT)) + wave * NSTRIP * STRIP;
     char* sA1 = sA0 + STRIP;
     char* sW = sA1 + STRIP;
     if constexpr (!WREG) {
@@ -255,7 +287,9 @@ __device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* pl
                 const long af1 = two ? *reinterpret_cast<const long*>(sA1 + o) : 0L;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const long wf = *reinterpret_cast<const long*>(sW + tt * STRIP + o);
+                    long wf;
+                    if constexpr (WREG) wf = wreg8[tt * KS + ks];
+                    else wf = *reinterpret_cast<const long*>(sW + tt * STRIP + o);
                     acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf, af0, acc0[tt], 0, 0, 0);
                     if (two) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf, af1, acc1[tt], 0, 0, 0);
                 }
@@ -267,7 +301,7 @@ __device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* pl
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     bf16x8 wf;
-                    if constexpr (WREG) wf = __builtin_bit_cast(bf16x8, wreg[ks]);
+                    if constexpr (WREG) wf = __builtin_bit_cast(bf16x8, wreg[tt * KS + ks]);
                     else wf = *reinterpret_cast<const bf16x8*>(sW + tt * STRIP + o);
                     acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af0, acc0[tt], 0, 0, 0);
                     if (two) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af1, acc1[tt], 0, 0, 0);
@@ -430,24 +464,30 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
         step = c.row_pos ? c.row_pos[mq < m_end ? mq : m_end - 1] : c.shared->step;
     }
     __builtin_amdgcn_sched_barrier(0);
-    // expert weights: stage 2 = hidden columns 64 ot .. + 63 of expert e2 (K = 512); stage 3 = output columns 16 ot .. + 15 of the same expert (K = 2048)
-    constexpr int NW_IN = FP8 ? 4 : Geo<512, 4>::NIW, NW_OUT = FP8 ? 4 : G2::KS;
-    u32x4 wi4[NW_IN], wo2[NW_OUT], w3[G1::NIW];
+    // expert weights: stage 2 = hidden columns 64 ot .. + 63 of expert e2 (K = 512), row layout; stage 3 = output columns 16 NT3 ct .. of the same
+    // expert (K = 2048) as MFMA fragments: lane (li, g) holds column li's k = 32 ks + 8 g .. + 7 of this wave's K-slice for every 16-column tile
+    constexpr int NT3 = FP8 ? 4 : 2;                          // stage 3: 16 NT3 columns per workgroup, the expert's pairs split NT3 ways (32 workgroups per expert either way)
+    const int ct = ot % (32 / NT3), part = ot / (32 / NT3);   // ot = ct + (32 / NT3) part: the NT3 parts of a column tile sit on one XCD (blockIdx & 7 == nt & 7) and share its weights in L2
+    constexpr int NW_IN = FP8 ? 4 : Geo<512, 4>::NIW;
+    u32x4 wi4[NW_IN], wo2[FP8 ? 16 : NT3 * G2::KS], w3[G1::NIW];   // fp8: wo2 = the 64 rows' K-slices in row layout (whole lines; fragments are made of them below)
+    long wo8[FP8 ? NT3 * G2::KS : 1];
     if constexpr (FP8) {
         const uint8_t* Wi = static_cast<const uint8_t*>(pWi);
         const uint8_t* Wo = static_cast<const uint8_t*>(pWo);
-        // fp8 rows: K bytes; this wave's K-slice = KW bytes, 16 bytes per lane: 4 lanes per row of the K = 512 tile, 16 per row of the K = 2048 tile
+        // fp8 rows: K bytes; this wave's K-slice = KW bytes, 16 bytes per lane: 4 lanes per row of the K = 512 tile
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
             wi4[tt] = *reinterpret_cast<const u32x4*>(Wi + ((size_t)e2 * 2048 + ot * 64 + tt * 16 + lane / 4) * 512 + wave * 64 + (lane % 4) * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            wo2[i] = *reinterpret_cast<const u32x4*>(Wo + ((size_t)e2 * 512 + ot * 16 + i * 4 + lane / 16) * 2048 + wave * 256 + (lane % 16) * 16);
+        for (int i = 0; i < 16; ++i)
+            wo2[i] = *reinterpret_cast<const u32x4*>(Wo + ((size_t)e2 * 512 + ct * 64 + i * 4 + lane / 16) * 2048 + wave * 256 + (lane % 16) * 16);
     } else {
         const bf16_t* Wi = static_cast<const bf16_t*>(pWi);
         const bf16_t* Wo = static_cast<const bf16_t*>(pWo);
         load_w<512, 4>(Wi + (size_t)e2 * 2048 * 512, ot * 64, wi4);
-        load_w_frag<2048>(Wo + (size_t)e2 * 512 * 2048, ot * 16, wo2);
+#pragma unroll
+        for (int tt = 0; tt < NT3; ++tt)
+            load_w_frag<2048>(Wo + (size_t)e2 * 512 * 2048, ct * 16 * NT3 + tt * 16, *reinterpret_cast<u32x4(*)[G2::KS]>(wo2 + tt * G2::KS));
     }
     load_w<512, 2>(pW3, nt3 * 32, w3);
     const f32x4 g3 = norm_gain(c.gain3);
@@ -495,28 +535,47 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     const int cnt = find_pairs(c.sel, 2 * R, e2, plist, wcnt);
     float ws_in = 1.f, ws_out = 1.f;
     if constexpr (FP8) { ws_in = c.wi_s[e2]; ws_out = c.wo_s[e2]; }
-    if (cnt) expert_pass<0, FP8>(c, plist, cnt, ot * 64, wi4, ws_in, smem);
+    if (cnt) expert_pass<0, FP8, 4>(c, plist, cnt, ot * 64, wi4, nullptr, ws_in, smem);
     mc_signal(c.sync, MC_FFN_IN + e2 * 8);
     CH_MARK(c, 4);
-    // ---- stage 3: expert FFN-out, 16 output columns of the same expert
+    if constexpr (FP8) {
+        // stage 3's weights from row layout to MFMA fragments through this wave's own strip space, 32 rows at a time (a wave's LDS accesses execute in
+        // order: no barrier).  (Fragment-shaped 8-byte global loads at entry cost stage 0 ~2 us: 16 cache lines per instruction.)
+        constexpr int WP = 256 + 16;
+        char* wl = smem + L_STRIPS + wave * 32 * WP;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(wl + (i * 4 + lane / 16) * WP + (lane % 16) * 16) = wo2[hh * 8 + i];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int ks = 0; ks < G2::KS; ++ks)
+                    wo8[(hh * 2 + t2) * G2::KS + ks] = *reinterpret_cast<const long*>(wl + (t2 * 16 + (lane & 15)) * WP + ks * 32 + (lane >> 4) * 8);
+        }
+    }
+    // ---- stage 3: expert FFN-out, 16 NT3 output columns of the same expert for part `part` of its pairs (ascending pair order within a part; a
+    // pair's outputs do not depend on which pairs it is grouped with).  Splitting the pairs, not only the columns, keeps the most popular expert's
+    // workgroups to one pass (<= 64 / NT3 pairs), and a hidden row is read by 32 / NT3 workgroups instead of 32
     {
         mc_wait(c.sync, MC_FFN_IN + e2 * 8, 32u, c.host_abort);
         CH_MARK(c, 5);
-        if (cnt) expert_pass<1, FP8>(c, plist, cnt, ot * 16, wo2, ws_out, smem);
-        mc_signal(c.sync, MC_FFN_OUT);
+        const int per = (cnt + NT3 - 1) / NT3, first = min(cnt, part * per), mine = min(cnt, first + per) - first;
+        if (mine > 0) expert_pass<1, FP8, NT3>(c, plist + first, mine, ct * 16 * NT3, wo2, wo8, ws_out, smem);
+        mc_signal(c.sync, MC_FFN_OUT + e2 * 8);
         CH_MARK(c, 6);
     }
     // ---- stage 4: the next layer's QKV projection (or lm_head) on h + (y0 + y1)
     if (has3) {
-        mc_wait(c.sync, MC_FFN_OUT, 256u, c.host_abort);
+        mc_wait8(c.sync, MC_FFN_OUT, 32u, c.host_abort);
         CH_MARK(c, 7);
         pend_tile<MODE3>(c, R, g3, nt3, mt, step, w3, smem);
     }
     CH_STAMP_OUT(c);
 }
 
-constexpr size_t MOE_CHAIN_LDS_BF16 = (size_t)L_STRIPS3 + (size_t)8 * 2 * 16 * (2048 / 8 * 2 + 16);                 // stage 3: two 16-row activation strips per wave (weights in registers)
-constexpr size_t MOE_CHAIN_LDS_FP8 = (size_t)L_STRIPS3 + (size_t)8 * 3 * 16 * (2048 / 8 + 16);                      // stage 3: two activation strips + the weight strip
+constexpr size_t MOE_CHAIN_LDS_BF16 = (size_t)l_strips3(2) + (size_t)8 * 2 * 16 * (2048 / 8 * 2 + 16);               // stage 3: two 16-row activation strips per wave (weights in registers)
+constexpr size_t MOE_CHAIN_LDS_FP8 = (size_t)l_strips3(4) + (size_t)8 * 2 * 16 * (2048 / 8 + 16);
 static_assert(MOE_CHAIN_LDS_BF16 >= (size_t)L_STRIPS + (size_t)8 * 6 * 16 * (512 / 8 * 2 + 16), "stage 2 (bf16): two activation + four weight strips per wave");
 static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS + (size_t)8 * 6 * 16 * (512 / 8 + 16), "stage 2 (fp8)");
 static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS + (size_t)8 * 3 * 16 * (512 / 8 * 2 + 16), "stages 0 and 4 (bf16 strips) in the fp8 kernel");
