@@ -72,20 +72,30 @@ __device__ __forceinline__ void load_w_frag(const bf16_t* W, int n0, u32x4 (&wf)
 __device__ __forceinline__ unsigned* chain_counter(unsigned* sync, int boundary, int mt, int replica) {
     return sync + ((boundary * CHAIN_TILES_MAX + mt) * 8 + replica) * CHAIN_LINE;
 }
-__device__ __forceinline__ void chain_wait(unsigned* sync, int boundary, int mt, unsigned target, unsigned* host_abort, unsigned* abort_at = nullptr) {
-    if (YMT3_TID == 0) {
-        const unsigned* cnt = chain_counter(sync, boundary, mt, blockIdx.x & 7);
+// With <= 4 row tiles (the merged regime: up to 64 rows) a (boundary, row tile) counter is split in FOUR by the producer's column tile (nt & 3), at
+// tile slots mt + 4 sub: adds to one line are served one after the other, and a stage's 32-64 producers finish together -- a quarter of them per
+// line makes the last arrival visible sooner.  The consumer polls its replica of all four with four lanes of one instruction.
+__device__ __forceinline__ void chain_wait(unsigned* sync, int boundary, int mt, unsigned target, unsigned* host_abort, unsigned* abort_at = nullptr, int nsub = 1) {
+    if (YMT3_TID < 64) {
+        const int lane = YMT3_TID;
+        const unsigned* cnt = chain_counter(sync, boundary, mt + 4 * (lane < nsub ? lane : 0), blockIdx.x & 7);
+        const unsigned each = target / (unsigned)nsub;
         unsigned* abort_word = abort_at ? abort_at : sync + CHAIN_ABORT_WORD;      // (dec_step.hip keeps one abort word for its per-layer counter sets)
         unsigned long long t0 = 0;
         unsigned polls = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        for (;;) {
+            unsigned v = each;
+            if (lane < nsub) v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(v < each) == 0ull) break;
             YMT3_POLL_PAUSE;
             if ((++polls & 63u) == 0u) {
                 const unsigned long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
                 if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > SPIN_LIMIT) {
-                    __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (host_abort) __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (lane == 0) {
+                        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (host_abort) __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     break;
                 }
             }
@@ -119,10 +129,10 @@ __device__ __forceinline__ void counter_signal(unsigned* cnt, int n, int stride)
     __syncthreads();
     if ((int)YMT3_TID < n) __hip_atomic_fetch_add(cnt + YMT3_TID * stride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void chain_signal(unsigned* sync, int boundary, int mt) {
+__device__ __forceinline__ void chain_signal(unsigned* sync, int boundary, int mt, int sub = 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's agent-scope stores have been acknowledged
     __syncthreads();
-    if (YMT3_TID < 8) __hip_atomic_fetch_add(chain_counter(sync, boundary, mt, YMT3_TID), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (YMT3_TID < 8) __hip_atomic_fetch_add(chain_counter(sync, boundary, mt + 4 * sub, YMT3_TID), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // strips -> MFMA -> fixed-order cross-wave reduction; returns this thread's two outputs (dec_gemm_kernel, from "fragment order read-back")
@@ -302,6 +312,9 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
     using G2 = Geo<2048, 1>;
     const int tid = YMT3_TID, lane = tid & 63, wave = tid >> 6;
     const int n_mt = (R + 15) / 16, m_end = row0 + R;
+    // counters split by the producer's column tile (chain_wait), per boundary
+    const int nsub_all = c.nsub ? c.nsub : 0x444;
+    const int nsub0 = n_mt <= 4 ? nsub_all & 15 : 1, nsub1 = n_mt <= 4 ? (nsub_all >> 4) & 15 : 1, nsub2 = n_mt <= 4 ? (nsub_all >> 8) & 15 : 1;
     // workgroup -> tile, the same in every stage, no divisions in front of the first loads: XCD = t & 7 (round-robin placement; speed
     // only), row tile = (t >> 3) & 3, column tile = (t >> 5) * 8 + XCD -- the workgroups that share a weight tile sit on one XCD, as
     // in dec_gemm_kernel.  A workgroup without a tile in a stage (row tile beyond R, column tile beyond the stage's N) still requests
@@ -399,17 +412,17 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
         }
         o0 = resid_out(hold, s, pH, c.ssq, c.ssq_stride, mE, nE, nt0, live0);
         CH_MARK(c, 0);
-        chain_signal(c.sync, 0, mt0);
+        chain_signal(c.sync, 0, mt0, nt0 & (nsub0 - 1));
         CH_MARK(c, 1);
     }
     // ---- stage 1: FFN-in
     if (has1) {
         norm_park<2>(smem, w1);
-        chain_wait(c.sync, 0, mt1, 32u, c.host_abort, c.sync_abort);
+        chain_wait(c.sync, 0, mt1, 32u, c.host_abort, c.sync_abort, nsub0);
         CH_MARK(c, 2);
         norm_tile<DG_NORM_BF16_RELU>(c, pH, row0, R, g1, c.d_ff, nt1, mt1, 0, smem);
         CH_MARK(c, 3);
-        chain_signal(c.sync, 1, mt1);
+        chain_signal(c.sync, 1, mt1, nt1 & (nsub1 - 1));
         CH_MARK(c, 4);
     }
     // ---- stage 2: FFN-out (the tile of stage 0 again: its h values are still in registers)
@@ -423,7 +436,7 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
             for (int i = 0; i < G2::NIW; ++i)          // the weight slices are parked while the FFN-in stage is still running
                 *reinterpret_cast<u32x4*>(sW + (i * G2::RPIW + lane / G2::LPRW) * G2::PITCH + (lane % G2::LPRW) * 16) = w2[i];
         }
-        chain_wait(c.sync, 1, mt0, (unsigned)(c.d_ff / 32), c.host_abort, c.sync_abort);
+        chain_wait(c.sync, 1, mt0, (unsigned)(c.d_ff / 32), c.host_abort, c.sync_abort, nsub1);
         CH_MARK(c, 5);
         const __amdgpu_buffer_rsrc_t ra = raw_rsrc(c.dff);
         u32x4 dv[G2::NIA];
@@ -441,12 +454,12 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
         else s = mfma_reduce<2048, 1>(sA, sA + G2::STRIP, red);
         resid_out(o0, s, pH, c.ssq, c.ssq_stride, mE, nE, nt0, live0);
         CH_MARK(c, 6);
-        chain_signal(c.sync, 2, mt0);
+        chain_signal(c.sync, 2, mt0, nt0 & (nsub2 - 1));
     }
     // ---- stage 3: the next layer's QKV projection, or lm_head
     if (has3) {
         norm_park<2>(smem, w3);
-        chain_wait(c.sync, 2, mt3, 32u, c.host_abort, c.sync_abort);
+        chain_wait(c.sync, 2, mt3, 32u, c.host_abort, c.sync_abort, nsub2);
         CH_MARK(c, 7);
         norm_tile<MODE3, INL>(c, pH, row0, R, g3, c.N3, nt3, mt3, step, smem);
     }

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
 // block.  Same epilogues as above (KV-cache append, ReLU, residual add + sum(h^2) partials per 16-column tile, logits).
 // K is accumulated in ONE MFMA chain per output (no 8-way split), so results differ from the 16-row kernel in the last
 // bits: the launcher switches on R alone, and rows stay independent of their batch inside either regime.
-template <int MODE, int K, int BM>
+template <int MODE, int K, int BM, int PF>
 __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restrict__ pW, const void* __restrict__ pX, const float* __restrict__ pGain,
                                                            float* pSsq, float* pOut, int row0, int R, int N, int ssq_stride, DecGemmArgs a) {
     constexpr bool NORM = (MODE != DG_RESID);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
 
     // staging registers, a ring of PF K-steps: W tile 64 x 128 B = 2 x 16 B per thread; A tile BM x 128 B (bf16) or BM x 256 B (fp32).
     // One step ahead left every step exposed to a full L2 / HBM round trip (22.6 us for K = 2048 at 832 rows, profiles/r02_notes.md)
-    constexpr int NWV = 2, NAB = BM / 32, NAF = BM / 16, PF = 4;
+    constexpr int NWV = 2, NAB = BM / 32, NAF = BM / 16;
     static_assert(NKT % PF == 0, "the K loop is unrolled by the prefetch depth");
     u32x4 wvr[PF][NWV];
     u32x4 abr[PF][NORM ? 1 : NAB];
@@ -426,10 +426,7 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
                 constexpr int PFm = PF - 1;
                 const int jn = (j + 1) & PFm;
                 // the other LDS stage: its last readers passed the barrier at the end of step kt - 1
-                if (jn == 0) store_lds(kt + 1, buf ^ 1, wvr[0], abr[0], afr[0]);
-                else if (jn == 1) store_lds(kt + 1, buf ^ 1, wvr[1], abr[1], afr[1]);
-                else if (jn == 2) store_lds(kt + 1, buf ^ 1, wvr[2], abr[2], afr[2]);
-                else store_lds(kt + 1, buf ^ 1, wvr[3], abr[3], afr[3]);
+                store_lds(kt + 1, buf ^ 1, wvr[jn], abr[jn], afr[jn]);          // (j is a constant after unrolling)
                 __syncthreads();
             }
         }
@@ -1133,7 +1130,8 @@ int init_decode_kernels() {
 template <int MODE, int K, int BM>
 int launch_dg_mid(const DecGemmArgs& a, hipStream_t stream) {
     if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;
-    dec_gemm_mid_kernel<MODE, K, BM><<<(a.N / 64) * ((a.R + BM - 1) / BM), 256, 0, stream>>>(
+    constexpr int PF = 8;     // K-steps of operands in flight per thread: all of K = 512
+    dec_gemm_mid_kernel<MODE, K, BM, PF><<<(a.N / 64) * ((a.R + BM - 1) / BM), 256, 0, stream>>>(
         a.W, MODE == DG_RESID ? static_cast<const void*>(a.a_bf16) : static_cast<const void*>(a.x_f32), a.gain, a.ssq, a.out_f32, a.row0, a.R, a.N,
         a.ssq_stride, a);
     return 0;

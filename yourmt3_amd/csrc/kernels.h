@@ -142,6 +142,7 @@ struct ChainArgs {
     unsigned* host_abort;       // pinned host word, set with the abort (the host refuses further calls)
     unsigned long long* stamp;
     unsigned* sync_abort;       // dec_step.hip only: the sticky abort word (the chain launch finds it at sync + CHAIN_ABORT_WORD)
+    int nsub;                   // measurement only: counters per boundary (1 / 2 / 4) in bits 0-3, 4-7, 8-11; 0 = the built-in choice
 };
 constexpr int CHAIN_LINE = 32;                                  // 32-bit words per 128-byte line
 constexpr int CHAIN_TILES_MAX = 16;                             // row tiles of 16 rows a chain launch can hold (256 rows)

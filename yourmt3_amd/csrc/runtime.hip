@@ -834,6 +834,7 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
             cg.out_q = h->dq; cg.kcache = h->kcache + (size_t)(l + 1) * layer_cache; cg.vcache = h->vcache + (size_t)(l + 1) * layer_cache;
             cg.logits = h->logits; cg.H = H; cg.L = L; cg.shared = shared; cg.row_pos = a.row_pos; cg.row0 = row0; cg.R = R; cg.eps = k.ln_eps;
             cg.sync = h->chain_sync; cg.host_abort = h->chain_host_abort;
+            { static const int nsub_env = [] { const char* e = getenv("YMT3_CHAIN_NSUB"); return e ? (int)strtol(e, nullptr, 16) : 0; }(); cg.nsub = nsub_env; }
             cg.stamp = next_stamp(h, PC_CHAIN, 256);
             PLAUNCH(PC_CHAIN, launch_dec_chain(cg, s));
             if (last) lm_done = true; else qkv_done = true;
