@@ -5,6 +5,7 @@ set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=8 > gpurun_out/r03_pytest_gpu.log 2>&1; echo "pytest exit=$?"; tail -12 gpurun_out/r03_pytest_gpu.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
 timeout -k 10 400 python bench.py --steps 3 --warmup 1 > gpurun_out/r03_bench.log 2>&1; echo "bench exit=$?"
 tail -1 gpurun_out/r03_bench.log > gpurun_out/r03_bench_line.json
 rm -rf gpurun_out/prof

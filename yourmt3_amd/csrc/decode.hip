@@ -1130,7 +1130,7 @@ int init_decode_kernels() {
 template <int MODE, int K, int BM>
 int launch_dg_mid(const DecGemmArgs& a, hipStream_t stream) {
     if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;
-    constexpr int PF = 8;     // K-steps of operands in flight per thread: all of K = 512
+    constexpr int PF = 4;     // K-steps of operands in flight per thread (8 = all of K = 512 was measured: no faster at 832 rows, ~1 % slower at 256: profiles/r03_notes.md)
     dec_gemm_mid_kernel<MODE, K, BM, PF><<<(a.N / 64) * ((a.R + BM - 1) / BM), 256, 0, stream>>>(
         a.W, MODE == DG_RESID ? static_cast<const void*>(a.a_bf16) : static_cast<const void*>(a.x_f32), a.gain, a.ssq, a.out_f32, a.row0, a.R, a.N,
         a.ssq_stride, a);
