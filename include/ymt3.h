@@ -133,6 +133,12 @@ int ymt3_last_decode_steps(ymt3_handle h);
 int ymt3_set_abort_recovery(ymt3_handle h, int mode);
 int ymt3_merged_fallbacks(ymt3_handle h);
 
+/* How many concurrent row ranges ("chains", each on a stream of the handle's own, joined into the caller's stream before the call returns
+ * control of it) the last ymt3_decode_greedy / ymt3_transcribe_segments call decoded its batch as.  1 except for 200-256 rows of one channel
+ * with the dense FFN, where two halves overlap (the attention kernels are bandwidth-bound there, the GEMMs between them latency-bound); the ids do
+ * not depend on it.  YMT3_CHAINS=n in the environment at ymt3_create fixes the number (1..8). */
+int ymt3_last_decode_chains(ymt3_handle h);
+
 /* Measurement hook (bench.py `roofline`): decode eagerly (no graph) and bracket every kernel launch of
  * every `stride`-th step (positions stride/2, 3*stride/2, ...) with HIP events on `stream`; synchronises the stream before returning.
  * Classes: 0 qkv+cache GEMM, 1 self-attention, 2 self O-proj, 3 cross Q GEMM, 4 cross-attention,

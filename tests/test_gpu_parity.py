@@ -805,6 +805,28 @@ def test_perceiver_tf_encoder_matches_oracle():
         _model(cfg.with_(ptf_d=96))
 
 
+def test_automatic_two_chains_at_many_rows_give_the_single_chain_ids():
+    """200-256 rows of one channel decode as two concurrent chains by default (runtime.hip: auto_chains -- 626 against 690 ms per batch of 256,
+    profiles/r03_chains_many_rows.txt); YMT3_CHAINS=1 keeps one.  Both run the same kernels on every row, so the ids are bit-identical."""
+    cfg = SMALL
+    B = 224
+    a = O.synthetic_audio(8, cfg, seed=11)
+    a = a.repeat(B // 8, 1) * torch.linspace(0.5, 1.0, B)[:, None]     # 224 different segments from 8
+    m_auto = _model(cfg, max_batch=B)
+    os.environ["YMT3_CHAINS"] = "1"
+    try:
+        m_one = _model(cfg, max_batch=B)
+    finally:
+        del os.environ["YMT3_CHAINS"]
+    e = m_one.encode(m_one.logmel(a.cuda()))
+    t_one = m_one.decode(e, 48).cpu()
+    t_auto = m_auto.decode(e, 48).cpu()
+    assert torch.equal(t_auto, t_one)
+    assert m_auto.last_decode_chains == 2 and m_one.last_decode_chains == 1
+    assert len({tuple(r.flatten().tolist()) for r in t_one}) > 8                  # (the rows are not copies of each other)
+    m_one.close(); m_auto.close()
+
+
 def test_two_concurrent_chains_and_unfused_query_path_give_identical_tokens(small):
     """YMT3_CHAINS / YMT3_NO_FUSEQ are read at create: rows are independent, so any split must be bit-identical;
     the fused and the separate query projection follow the same rounding points (ids equal where margins allow)."""

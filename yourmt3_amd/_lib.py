@@ -16,7 +16,7 @@ SYMBOLS = [
     "ymt3_abi_version", "ymt3_last_error", "ymt3_create", "ymt3_destroy", "ymt3_device_bytes",
     "ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm", "ymt3_profile_decode", "ymt3_debug_decode_start", "ymt3_debug_force_stage_abort", "ymt3_set_early_stop", "ymt3_last_decode_steps",
     "ymt3_ingest_plan", "ymt3_ingest", "ymt3_transcribe_stream", "ymt3_debug_step_stamps", "ymt3_debug_kernel_stamps",
-    "ymt3_set_abort_recovery", "ymt3_merged_fallbacks", "ymt3_debug_moe_trace",
+    "ymt3_set_abort_recovery", "ymt3_merged_fallbacks", "ymt3_debug_moe_trace", "ymt3_last_decode_chains",
 ]
 
 _lib = None
@@ -78,6 +78,8 @@ def load() -> ctypes.CDLL:
     lib.ymt3_set_abort_recovery.restype = i32
     lib.ymt3_merged_fallbacks.argtypes = [vp]
     lib.ymt3_merged_fallbacks.restype = i32
+    lib.ymt3_last_decode_chains.argtypes = [vp]
+    lib.ymt3_last_decode_chains.restype = i32
     lib.ymt3_debug_moe_trace.argtypes = [vp, vp, i32, i32]
     lib.ymt3_debug_moe_trace.restype = i32
     for n in ("ymt3_logmel", "ymt3_encode", "ymt3_decode_greedy", "ymt3_transcribe_segments", "ymt3_test_gemm"):

@@ -96,6 +96,12 @@ struct ymt3_ctx {
     // per batch against 279.8 for one, 3 / 4 chains 474 / 486 ms -- so the chains do not overlap on the device either.
     // Default 1; YMT3_CHAINS overrides (kept as a tested option: any row split must give identical ids).
     int n_chains = 1;
+    // Round 3, many rows: with 200-256 rows of one channel the attention kernels are bandwidth-bound and the GEMMs between them latency-bound, and
+    // two chains of 100-128 rows do overlap: 626 against 690 ms per batch of 256 (profiles/r03_chains_many_rows.txt; equal at 192 rows, slower from
+    // 512).  `auto_chains` (YMT3_CHAINS unset) takes two chains exactly there -- both halves and the whole stay in the same kernel regime (8-wave
+    // attention, 16-row-tile GEMMs, no folded O-projection), so the ids do not depend on the choice (tested).
+    bool auto_chains = true;
+    int last_chains = 1;
     bool chain_threads = true;              // one launcher thread per chain (YMT3_CHAIN_THREADS=0: the caller's thread feeds all)
     hipStream_t chain_stream[8] = {};
     hipEvent_t fork_ev = nullptr, join_ev[8] = {};
@@ -427,10 +433,10 @@ static int create_impl(ymt3_ctx* c, const ymt3_config* cfg, const void* blob, si
     { const char* tf = getenv("YMT3_STEP_TILES_FREE"); c->step_tiles_free = tf && tf[0] == '1'; }
     if (const char* ar = getenv("YMT3_ABORT_RECOVERY")) c->abort_recovery = ar[0] == '0' ? 0 : 1;
     const char* nc = getenv("YMT3_CHAINS");
-    if (nc && atoi(nc) >= 1) c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc);
+    if (nc && atoi(nc) >= 1) { c->n_chains = atoi(nc) > 8 ? 8 : atoi(nc); c->auto_chains = false; }
     const char* ct = getenv("YMT3_CHAIN_THREADS");
     c->chain_threads = !(ct && ct[0] == '0');
-    for (int i = 0; i < c->n_chains; ++i) {
+    for (int i = 0; i < std::max(c->n_chains, 2); ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&c->chain_stream[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
     }
@@ -939,7 +945,11 @@ static int decode_run(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int3
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&a.chan_embed), (size_t)k.n_channels * d);
     // chains: contiguous, near-equal row ranges
     int n_chains = (!h->use_graph || prof_stride > 0 || k.dec_ffn == YMT3_FFN_MOE) ? 1 : h->n_chains;   // MoE pair tables are per handle
+    if (h->auto_chains && n_chains == 1 && h->use_graph && prof_stride == 0 && k.dec_ffn != YMT3_FFN_MOE && k.n_channels == 1 && R >= 200 && R <= 256 &&
+        !(h->early_stop_interval > 0 && k.eos_id >= 0 && !forced))
+        n_chains = 2;
     if (n_chains > R) n_chains = R;
+    h->last_chains = n_chains;
     if (h->step_kernel && h->step_sync) HIP_TRY(hipMemsetAsync(h->step_sync, 0, (size_t)STEP_SYNC_LINES * CHAIN_LINE * sizeof(unsigned), s));
     LAUNCH(launch_decode_init(a, n_chains, n_steps, step0, tokens, forced, logits_out, s));
     h->last_steps = n_steps;
@@ -1449,6 +1459,7 @@ extern "C" int ymt3_ingest(ymt3_handle h, const void* pcm_dev, int pcm_format, i
 extern "C" int ymt3_last_decode_steps(ymt3_handle h) { return h ? h->last_steps : 0; }
 
 extern "C" int ymt3_merged_fallbacks(ymt3_handle h) { return h ? h->fallback_count : 0; }
+extern "C" int ymt3_last_decode_chains(ymt3_handle h) { return h ? h->last_chains : 0; }
 
 extern "C" int ymt3_set_abort_recovery(ymt3_handle h, int mode) {
     if (!h) FAIL(YMT3_ERR_ARG, "null handle");

@@ -78,6 +78,11 @@ class YourMT3:
         """How often this handle left the merged decode kernels for the separate launches after one gave up waiting (0 or 1)."""
         return int(self._lib.ymt3_merged_fallbacks(self._handle))
 
+    @property
+    def last_decode_chains(self) -> int:
+        """Concurrent row ranges the last decode call cut its batch into (include/ymt3.h: 2 for 200-256 rows of one channel, else 1)."""
+        return int(self._lib.ymt3_last_decode_chains(self._handle))
+
     def set_abort_recovery(self, mode: int) -> None:
         """1 (default): decode calls verify at their end that no merged kernel gave up and re-run through the separate launches if
         one did; 0: fully asynchronous calls, an aborted call's ids are INT32_MIN and the next call switches over (include/ymt3.h)."""
