@@ -305,17 +305,23 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(const bf16_t* __restrict_
 // block.  Same epilogues as above (KV-cache append, ReLU, residual add + sum(h^2) partials per 16-column tile, logits).
 // K is accumulated in ONE MFMA chain per output (no 8-way split), so results differ from the 16-row kernel in the last
 // bits: the launcher switches on R alone, and rows stay independent of their batch inside either regime.
-template <int MODE, int K, int BM, int PF>
-__global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restrict__ pW, const void* __restrict__ pX, const float* __restrict__ pGain,
+template <int MODE, int K, int BM, int PF, int NTH>
+__global__ __launch_bounds__(NTH) void dec_gemm_mid_kernel(const bf16_t* __restrict__ pW, const void* __restrict__ pX, const float* __restrict__ pGain,
                                                            float* pSsq, float* pOut, int row0, int R, int N, int ssq_stride, DecGemmArgs a) {
     constexpr bool NORM = (MODE != DG_RESID);
     constexpr int BN = 64, BK = 64, MT = BM / 16, PITCH = BK * 2 + 16, NKT = K / BK;
+    // NTH = 512: two waves per SIMD, each with half of the row tiles of its 16 columns (wave & 3: columns, wave >> 2: row tiles) -- with one wave per
+    // SIMD every LDS read, MFMA and barrier of a K-step was exposed (K = 2048 at 832 rows: 8.5 -> ... us, profiles/r03_notes.md)
+    constexpr int RG = NTH / 256, MTW = MT / RG;
+    static_assert(NTH == 256 || NTH == 512, "");
+    static_assert(MT % RG == 0, "row tiles split between the two wave groups");
     constexpr int A_STAGE = BM * PITCH, W_STAGE = BN * PITCH;
     __shared__ __attribute__((aligned(16))) char sA[2][A_STAGE];
     __shared__ __attribute__((aligned(16))) char sW[2][W_STAGE];
     __shared__ float sscale[BM];
     __shared__ __attribute__((aligned(16))) float sgain[NORM ? K : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int wc = wave & 3, rg = wave >> 2;
     const int n_mt = (R + BM - 1) / BM, n_nt = N / BN;
     int nt_idx, mt_idx;
     if ((n_nt & 7) == 0) {                       // blocks with equal blockIdx % 8 (one XCD; speed only) walk the row tiles of one column tile
@@ -330,7 +336,8 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
 
     // staging registers, a ring of PF K-steps: W tile 64 x 128 B = 2 x 16 B per thread; A tile BM x 128 B (bf16) or BM x 256 B (fp32).
     // One step ahead left every step exposed to a full L2 / HBM round trip (22.6 us for K = 2048 at 832 rows, profiles/r02_notes.md)
-    constexpr int NWV = 2, NAB = BM / 32, NAF = BM / 16;
+    constexpr int NWV = 512 / NTH, NAB = (BM * 8 + NTH - 1) / NTH, NAF = BM * 16 / NTH;
+    static_assert(BM * 16 % NTH == 0, "");
     static_assert(NKT % PF == 0, "the K loop is unrolled by the prefetch depth");
     u32x4 wvr[PF][NWV];
     u32x4 abr[PF][NORM ? 1 : NAB];
@@ -338,13 +345,13 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
     auto load_regs = [&](int kt, u32x4 (&wv)[NWV], u32x4 (&ab)[NORM ? 1 : NAB], f32x4 (&af)[NORM ? NAF : 1]) {
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
-            const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+            const int idx = tid + i * NTH, row = idx >> 3, ch = idx & 7;
             wv[i] = *reinterpret_cast<const u32x4*>(pW + (size_t)(n0 + row) * K + kt * BK + ch * 8);
         }
         if constexpr (NORM) {
 #pragma unroll
             for (int i = 0; i < NAF; ++i) {
-                const int idx = tid + i * 256, row = idx >> 4, ch = idx & 15;
+                const int idx = tid + i * NTH, row = idx >> 4, ch = idx & 15;
                 int mm = m0 + row;
                 mm = mm < m_end ? mm : m_end - 1;
                 af[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(pX) + (size_t)mm * K + kt * BK + ch * 4);
@@ -352,23 +359,24 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
         } else {
 #pragma unroll
             for (int i = 0; i < NAB; ++i) {
-                const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+                const int idx = tid + i * NTH, row = idx >> 3, ch = idx & 7;
                 int mm = m0 + row;
                 mm = mm < m_end ? mm : m_end - 1;
-                ab[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(pX) + (size_t)mm * K + kt * BK + ch * 8);
+                if (BM * 8 % NTH == 0 || idx < BM * 8)  // (BM = 32 with 512 threads: half of them carry a chunk)
+                    ab[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(pX) + (size_t)mm * K + kt * BK + ch * 8);
             }
         }
     };
     auto store_lds = [&](int kt, int buf, const u32x4 (&wv)[NWV], const u32x4 (&ab)[NORM ? 1 : NAB], const f32x4 (&af)[NORM ? NAF : 1]) {
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
-            const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+            const int idx = tid + i * NTH, row = idx >> 3, ch = idx & 7;
             *reinterpret_cast<u32x4*>(sW[buf] + row * PITCH + ch * 16) = wv[i];
         }
         if constexpr (NORM) {
 #pragma unroll
             for (int i = 0; i < NAF; ++i) {
-                const int idx = tid + i * 256, row = idx >> 4, ch = idx & 15;
+                const int idx = tid + i * NTH, row = idx >> 4, ch = idx & 15;
                 const float sc = sscale[row];
                 const f32x4 gv = *reinterpret_cast<const f32x4*>(sgain + kt * BK + ch * 4);
                 *reinterpret_cast<uint2*>(sA[buf] + row * PITCH + ch * 8) =
@@ -377,37 +385,56 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
         } else {
 #pragma unroll
             for (int i = 0; i < NAB; ++i) {
-                const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
-                *reinterpret_cast<u32x4*>(sA[buf] + row * PITCH + ch * 16) = ab[i];
+                const int idx = tid + i * NTH, row = idx >> 3, ch = idx & 7;
+                if (BM * 8 % NTH == 0 || idx < BM * 8) *reinterpret_cast<u32x4*>(sA[buf] + row * PITCH + ch * 16) = ab[i];
             }
         }
     };
 
+    // requested in the order of first use (vector loads return in order): the norm's inputs -- the sum(h^2) partials of this thread's row, the gain
+    // vector -- then the operand ring
+    float ss = 0.f;
+    f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NORM) {
+        static_assert(K / 4 <= NTH, "one float4 of the gain vector per thread");
+        if (tid < K / 4) gv = *reinterpret_cast<const f32x4*>(pGain + tid * 4);
+        if (tid < BM * 4) {
+            const int row = tid >> 2;
+            const int mm = m0 + row < m_end ? m0 + row : m_end - 1;
+#pragma unroll
+            for (int j = 0; j < SSQ_TILES / 4; ++j) ss += pSsq[(size_t)((tid & 3) * (SSQ_TILES / 4) + j) * ssq_stride + mm];
+        }
+    }
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_regs(p, wvr[p], abr[p], afr[p]);
     int step = 0;
     if constexpr (MODE == DG_NORM_QKV_CACHE) step = a.row_pos ? 0 : a.shared->step;       // per-row positions are read in the epilogue
     if constexpr (NORM) {
         // row scales from the carried partials (4 threads per row, 8 partials each, then the 4-lane sum) and the gain vector
-        for (int i = tid; i < K / 4; i += 256) *reinterpret_cast<f32x4*>(sgain + i * 4) = *reinterpret_cast<const f32x4*>(pGain + i * 4);
+        if (tid < K / 4) *reinterpret_cast<f32x4*>(sgain + tid * 4) = gv;
         if (tid < BM * 4) {
-            const int row = tid >> 2;
-            const int mm = m0 + row < m_end ? m0 + row : m_end - 1;
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < SSQ_TILES / 4; ++j) ss += pSsq[(size_t)((tid & 3) * (SSQ_TILES / 4) + j) * ssq_stride + mm];
             ss = add_xor2(add_xor1(ss));
-            if ((tid & 3) == 0) sscale[row] = rsqrtf(ss / (float)K + a.eps);
+            if ((tid & 3) == 0) sscale[tid >> 2] = rsqrtf(ss / (float)K + a.eps);
         }
         __syncthreads();
+    }
+    // DG_RESID: the residual values this lane will add to are requested now, behind the operand ring, not in the epilogue (a dependent round trip there)
+    float4 resid[MODE == DG_RESID ? MTW : 1];
+    if constexpr (MODE == DG_RESID) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int m = m0 + (rg * MTW + mt) * 16 + li;
+            resid[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end) resid[mt] = *reinterpret_cast<const float4*>(pOut + (size_t)m * N + n0 + wc * 16 + g * 4);
+        }
     }
     STAMP_IN(a);
     store_lds(0, 0, wvr[0], abr[0], afr[0]);
     __syncthreads();
 
-    f32x4 acc[MT];
+    f32x4 acc[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kt0 = 0; kt0 < NKT; kt0 += PF) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {             // ring slot j holds step kt0 + j; after its LDS store it is refilled with step kt + PF
@@ -415,10 +442,10 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
             if (kt + PF < NKT) load_regs(kt + PF, wvr[j], abr[j], afr[j]);     // slot j went to LDS one step ago (or before the loop)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW[buf] + (wave * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW[buf] + (wc * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA[buf] + (mt * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA[buf] + ((rg * MTW + mt) * 16 + li) * PITCH + (ks * 32 + g * 8) * 2);
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[mt], 0, 0, 0);
                 }
             }
@@ -433,24 +460,24 @@ __global__ __launch_bounds__(256) void dec_gemm_mid_kernel(const bf16_t* __restr
     }
 
     // epilogue: lane (li, g) of wave w holds row m0 + mt*16 + li, columns n0 + 16w + 4g .. +3
-    const int n = n0 + wave * 16 + g * 4;
+    const int n = n0 + wc * 16 + g * 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + mt * 16 + li;
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int m = m0 + (rg * MTW + mt) * 16 + li;
         const bool live = m < m_end;
         f32x4 s = acc[mt];
         if constexpr (MODE == DG_RESID) {
             float q = 0.f;
             if (live) {
                 float4* dst = reinterpret_cast<float4*>(pOut + (size_t)m * N + n);
-                float4 o = *dst;
+                float4 o = resid[mt];
                 o.x += s[0]; o.y += s[1]; o.z += s[2]; o.w += s[3];
                 *dst = o;
                 q = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
             }
             q += lane_xor16(q);                   // the four lanes (g) that hold this row's 16 columns of the tile
             q += lane_xor32(q);
-            if (live && g == 0) pSsq[(size_t)(n0 / 16 + wave) * ssq_stride + m] = q;
+            if (live && g == 0) pSsq[(size_t)(n0 / 16 + wc) * ssq_stride + m] = q;
         } else if constexpr (MODE == DG_NORM_LOGITS) {
             if (live) *reinterpret_cast<float4*>(pOut + (size_t)m * N + n) = make_float4(s[0], s[1], s[2], s[3]);
         } else if (live) {
@@ -1130,8 +1157,9 @@ int init_decode_kernels() {
 template <int MODE, int K, int BM>
 int launch_dg_mid(const DecGemmArgs& a, hipStream_t stream) {
     if (MODE == DG_RESID && a.N != 16 * SSQ_TILES) return -3;
-    constexpr int PF = 4;     // K-steps of operands in flight per thread (8 = all of K = 512 was measured: no faster at 832 rows, ~1 % slower at 256: profiles/r03_notes.md)
-    dec_gemm_mid_kernel<MODE, K, BM, PF><<<(a.N / 64) * ((a.R + BM - 1) / BM), 256, 0, stream>>>(
+    constexpr int PF = 4;     // K-steps of operands in flight per thread (8 = all of K = 512 and 2 were measured: profiles/r03_notes.md)
+    constexpr int NTH = 256;  // (512 -- two waves per SIMD, half the row tiles each -- was measured: K = 512 forms 0.5 us slower, K = 2048 twice as slow: profiles/r03_notes.md)
+    dec_gemm_mid_kernel<MODE, K, BM, PF, NTH><<<(a.N / 64) * ((a.R + BM - 1) / BM), NTH, 0, stream>>>(
         a.W, MODE == DG_RESID ? static_cast<const void*>(a.a_bf16) : static_cast<const void*>(a.x_f32), a.gain, a.ssq, a.out_f32, a.row0, a.R, a.N,
         a.ssq_stride, a);
     return 0;

@@ -42,8 +42,28 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(const float* __restr
     const int nc = n_channels, r0 = row0 + seg * nc;
     const size_t slab = ((size_t)seg * a.H + h) * T * DKV;
 
-    // --- everything that does not depend on the projection goes in flight first: K fragments, V rows, Wq fragments
+    // --- every operand is requested now, in the order of first use (vector loads return in order): the norm's inputs (sum(h^2) partials, the
+    // channel rows, the gain), the head's query-projection fragments, then the K fragments and the V rows, which stay in flight under the projection
+    float ss = 0.f;
+    {
+        const int row = tid >> 4, part = tid & 15;
+        if (row < nc) ss = pSsq[(size_t)(2 * part) * a.ssq_stride + r0 + row] + pSsq[(size_t)(2 * part + 1) * a.ssq_stride + r0 + row];
+    }
+    float4 xr[4][2], gr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) gr[i] = reinterpret_cast<const float4*>(pGain)[lane + 64 * i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave + 4 * j;
+            xr[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nc) xr[j][i] = reinterpret_cast<const float4*>(pX + (size_t)(r0 + row) * 512)[lane + 64 * i];
+        }
     u32x4 kf[NKT][2], vv[KPW / 8], wf[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+        wf[ks] = *reinterpret_cast<const u32x4*>(pWq + ((size_t)h * DKV + wave * 16 + li) * 512 + ks * 32 + g * 8);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -52,36 +72,30 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < KPW / 8; ++i)
         vv[i] = *reinterpret_cast<const u32x4*>(pV + slab + (size_t)(wave * KPW + i * 8 + (lane >> 3)) * DKV + (lane & 7) * 8);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-        wf[ks] = *reinterpret_cast<const u32x4*>(pWq + ((size_t)h * DKV + wave * 16 + li) * 512 + ks * 32 + g * 8);
+    __builtin_amdgcn_sched_barrier(0);
 
     // --- RMS norm of the channel rows into LDS (rows >= n_channels are zero)
     {
         const int row = tid >> 4, part = tid & 15;
-        float ss = 0.f;
-        if (row < nc) ss = pSsq[(size_t)(2 * part) * a.ssq_stride + r0 + row] + pSsq[(size_t)(2 * part + 1) * a.ssq_stride + r0 + row];
         ss = add_xor8(sum8(ss));                 // lanes ^1, ^2, ^4, ^8 by DPP moves (common.h): same pairs, same bits
         if (part == 0) sscale[row] = rsqrtf(ss / 512.f + a.eps);
     }
     __syncthreads();
-    for (int row = wave; row < 16; row += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave + 4 * j;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             uint2 pk = make_uint2(0u, 0u);
             if (row < nc) {
-                const float4 v = reinterpret_cast<const float4*>(pX + (size_t)(r0 + row) * 512)[lane + 64 * i];
-                const float4 gg = reinterpret_cast<const float4*>(pGain)[lane + 64 * i];
+                const float4 v = xr[j][i];
+                const float4 gg = gr[i];
                 const float sc = sscale[row];
                 pk = make_uint2(pack_bf16x2(v.x * sc * gg.x, v.y * sc * gg.y), pack_bf16x2(v.z * sc * gg.z, v.w * sc * gg.w));
             }
             *reinterpret_cast<uint2*>(xs + row * XP + (lane + 64 * i) * 4) = pk;
         }
     }
-    // the wave's V rows -> its private strip (consumed by transposed reads after the softmax)
-    bf16_t* myV = sV + wave * KPW * QP;
-#pragma unroll
-    for (int i = 0; i < KPW / 8; ++i) *reinterpret_cast<u32x4*>(myV + (i * 8 + (lane >> 3)) * QP + (lane & 7) * 8) = vv[i];
     __syncthreads();
 
     // --- query projection: wave w owns head dims 16w .. 16w+15
@@ -128,6 +142,11 @@ __global__ __launch_bounds__(256) void mc_cross_attn_kernel(const float* __restr
     sum += lane_xor16(sum);
     sum += lane_xor32(sum);
     if (g == 0) ssum[wave * 16 + li] = sum;
+
+    // the wave's V rows -> its private strip, consumed by this wave's transposed reads below (a wave's LDS accesses execute in order: no barrier)
+    bf16_t* myV = sV + wave * KPW * QP;
+#pragma unroll
+    for (int i = 0; i < KPW / 8; ++i) *reinterpret_cast<u32x4*>(myV + (i * 8 + (lane >> 3)) * QP + (lane & 7) * 8) = vv[i];
 
     // --- partial O^T over this wave's keys: k-step = key tiles (2kp, 2kp+1); P as hi + lo bf16 terms
     f32x4 o[4];
