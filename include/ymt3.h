@@ -134,7 +134,7 @@ int ymt3_set_abort_recovery(ymt3_handle h, int mode);
 int ymt3_merged_fallbacks(ymt3_handle h);
 
 /* How many concurrent row ranges ("chains", each on a stream of the handle's own, joined into the caller's stream before the call returns
- * control of it) the last ymt3_decode_greedy / ymt3_transcribe_segments call decoded its batch as.  1 except for 200-256 rows of one channel
+ * control of it) the last ymt3_decode_greedy / ymt3_transcribe_segments call decoded its batch as.  1 except for 168-256 rows of one channel
  * with the dense FFN, where two halves overlap (the attention kernels are bandwidth-bound there, the GEMMs between them latency-bound); the ids do
  * not depend on it.  YMT3_CHAINS=n in the environment at ymt3_create fixes the number (1..8). */
 int ymt3_last_decode_chains(ymt3_handle h);

@@ -806,7 +806,7 @@ def test_perceiver_tf_encoder_matches_oracle():
 
 
 def test_automatic_two_chains_at_many_rows_give_the_single_chain_ids():
-    """200-256 rows of one channel decode as two concurrent chains by default (runtime.hip: auto_chains -- 626 against 690 ms per batch of 256,
+    """168-256 rows of one channel decode as two concurrent chains by default (runtime.hip: auto_chains -- 626 against 690 ms per batch of 256,
     profiles/r03_chains_many_rows.txt); YMT3_CHAINS=1 keeps one.  Both run the same kernels on every row, so the ids are bit-identical."""
     cfg = SMALL
     B = 224

@@ -96,8 +96,8 @@ struct ymt3_ctx {
     // per batch against 279.8 for one, 3 / 4 chains 474 / 486 ms -- so the chains do not overlap on the device either.
     // Default 1; YMT3_CHAINS overrides (kept as a tested option: any row split must give identical ids).
     int n_chains = 1;
-    // Round 3, many rows: with 200-256 rows of one channel the attention kernels are bandwidth-bound and the GEMMs between them latency-bound, and
-    // two chains of 100-128 rows do overlap: 626 against 690 ms per batch of 256 (profiles/r03_chains_many_rows.txt; equal at 192 rows, slower from
+    // Round 3, many rows: with 168-256 rows of one channel the attention kernels are bandwidth-bound and the GEMMs between them latency-bound, and
+    // two chains of 84-128 rows do overlap: 626 against 690 ms per batch of 256, -6 % at 176 and 192 (profiles/r03_chains_many_rows.txt; -1 % at 160, slower from
     // 512).  `auto_chains` (YMT3_CHAINS unset) takes two chains exactly there -- both halves and the whole stay in the same kernel regime (8-wave
     // attention, 16-row-tile GEMMs, no folded O-projection), so the ids do not depend on the choice (tested).
     bool auto_chains = true;
@@ -720,7 +720,9 @@ static int launch_step(ymt3_handle h, int B, int row0, int R, DecodeShared* shar
     // and pays only while the per-(row, head) pull of wo (64 KB each) stays small against the launch it removes: +0.3 % at 64 rows,
     // -1.4 % at 128, -3.5 % at 256 (profiles/r02_b256_fold_fuseq_variants.txt); same bits either way
     const bool merged_rows = solo && k.n_channels == 1 && row0 == 0 && R <= h->merged_max_rows && h->attn_pair && h->pair_rows;     // (the pair kernel keeps the fold worthwhile beyond 96 rows)
-    const bool fold = h->fold_o && h->fuse_q && !mc && !h->force_2wave && H == 8 && d == 512 && (R <= 96 || merged_rows);
+    // (not for one of several concurrent chains: its 64 KB weight pulls per (row, head) share the chip badly -- two 96-row halves with it are no
+    // faster than one 192-row chain, without it 6 % faster: profiles/r03_chains_many_rows.txt)
+    const bool fold = h->fold_o && h->fuse_q && !mc && !h->force_2wave && H == 8 && d == 512 && ((R <= 96 && solo) || merged_rows);
     // The merged kernels' regime: one channel, up to 64 rows, and this step the only decode stream of the handle (`solo`: with YMT3_CHAINS > 1
     // other row ranges replay on other streams, and the merged kernels need every CU for their own workgroups while they run).
     const bool merged_regime = fold && solo && k.n_channels == 1 && R <= h->merged_max_rows && row0 == 0;
@@ -945,7 +947,7 @@ static int decode_run(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int3
     if (k.n_channels > 1) GET(h, "dec.chan_embed", 1u, const_cast<bf16_t**>(&a.chan_embed), (size_t)k.n_channels * d);
     // chains: contiguous, near-equal row ranges
     int n_chains = (!h->use_graph || prof_stride > 0 || k.dec_ffn == YMT3_FFN_MOE) ? 1 : h->n_chains;   // MoE pair tables are per handle
-    if (h->auto_chains && n_chains == 1 && h->use_graph && prof_stride == 0 && k.dec_ffn != YMT3_FFN_MOE && k.n_channels == 1 && R >= 200 && R <= 256 &&
+    if (h->auto_chains && n_chains == 1 && h->use_graph && prof_stride == 0 && k.dec_ffn != YMT3_FFN_MOE && k.n_channels == 1 && R >= 168 && R <= 256 &&
         !(h->early_stop_interval > 0 && k.eos_id >= 0 && !forced))
         n_chains = 2;
     if (n_chains > R) n_chains = R;

@@ -80,7 +80,7 @@ class YourMT3:
 
     @property
     def last_decode_chains(self) -> int:
-        """Concurrent row ranges the last decode call cut its batch into (include/ymt3.h: 2 for 200-256 rows of one channel, else 1)."""
+        """Concurrent row ranges the last decode call cut its batch into (include/ymt3.h: 2 for 168-256 rows of one channel, else 1)."""
         return int(self._lib.ymt3_last_decode_chains(self._handle))
 
     def set_abort_recovery(self, mode: int) -> None:
