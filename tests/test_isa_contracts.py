@@ -116,3 +116,32 @@ def test_step_kernel_keeps_the_counted_wait_and_fits_two_per_cu(step_asm):
     spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
     scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
     assert vgpr <= 128 and spill == 0 and scratch == 0, (vgpr, spill, scratch)
+
+
+def _asm(tmp_path_factory, name):
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    from yourmt3_amd import build as B
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    flags = [f for f in B.FLAGS if f not in ("-fPIC",)]
+    cmd = [hipcc] + flags + ["-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "yourmt3_amd", "csrc", name + ".hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    return out.read_text()
+
+
+def test_moe_chain_kernels_fit_one_workgroup_per_cu_without_scratch(tmp_path_factory):
+    """moe_chain_kernel keeps every later stage's weights in registers from entry (249 VGPRs in the bf16 form): a spill would put scratch traffic on
+    the chain's critical path, and more than 256 VGPRs (512 threads: two waves per SIMD) or 160 KB of LDS would make the launch fail.  Four
+    instantiations: QKV / lm_head tail x bf16 / fp8."""
+    asm = _asm(tmp_path_factory, "moe_chain")
+    metas = re.findall(r"\.name:\s+(\S*moe_chain_kernel\S*)\n(.*?)\.wavefront_size", asm, re.S)
+    assert len(metas) == 4, [m[0] for m in metas]
+    for name, meta in metas:
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
+        assert vgpr <= 256 and spill == 0 and scratch == 0, (name, vgpr, spill, scratch)
+    # the dynamic LDS block is set by the launcher from these constants: stage 3's two 16-row strips per wave behind the reduction space
+    src = open(os.path.join(ROOT, "yourmt3_amd", "csrc", "moe_chain.hip")).read()
+    assert "static_assert(MOE_CHAIN_LDS_BF16 <= 160 * 1024 && MOE_CHAIN_LDS_FP8 <= 160 * 1024" in src
