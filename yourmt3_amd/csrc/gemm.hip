@@ -239,7 +239,7 @@ constexpr int STAGE_BYTES = (TM + TN) * BK * 2;      // 48 KB: A rows, then W ro
 #define WAIT_DMA_AND_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_big_kernel(GemmArgs g) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -298,6 +298,22 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
     issue_next();
     if (total > 1) WAIT_DMA_AND_BARRIER(6); else WAIT_DMA_AND_BARRIER(0);
     int st = 0, left = total;                                            // compute side: stage being read, steps not yet computed
+    // The fragments of a K-step's two 32-wide halves are read one half AHEAD of the MFMAs that use them: half 1 of a step under the MFMAs of its
+    // half 0, half 0 of the NEXT step (its stage visible since the barrier in the middle of this one) under the MFMAs of half 1 -- also through
+    // tile boundaries and epilogues.  (hipcc's own schedule kept 24 fragment registers and waited for an LDS read in front of every group of
+    // four MFMAs: 0.28-0.30 MFMA utilisation in situ, profiles/r03_pmc_encoder.json.)
+    auto read_frags = [&](int stage, int ks, bf16x8 (&fa)[4], bf16x8 (&fw)[4]) {
+        const u32x4* sA = reinterpret_cast<const u32x4*>(smem + stage * STAGE_BYTES);
+        const u32x4* sW = sA + TM * 8;
+        const int ch = ks * 4 + (lane >> 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fa[t] = __builtin_bit_cast(bf16x8, sA[swz(wm * 64 + t * 16 + (lane & 15), ch)]);
+            fw[t] = __builtin_bit_cast(bf16x8, sW[swz(wn * 64 + t * 16 + (lane & 15), ch)]);
+        }
+    };
+    bf16x8 fa0[4], fw0[4];
+    read_frags(0, 0, fa0, fw0);
     for (int tile = t_first; tile < t_end; tile += t_stride) {
         f32x4 acc[4][4];
 #pragma unroll
@@ -310,34 +326,28 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
 #ifndef YMT3_PROBE_NO_DMA
             issue_next();                                                // step + 2: into the stage read one step ago
 #endif
-            const u32x4* sA = reinterpret_cast<const u32x4*>(smem + st * STAGE_BYTES);
-            const u32x4* sW = sA + TM * 8;
+            bf16x8 fa1[4], fw1[4];
+            read_frags(st, 1, fa1, fw1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[4], fw[4];
-                const int ch = ks * 4 + (lane >> 4);
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int ar = wm * 64 + t * 16 + (lane & 15);
-                    const int wr = wn * 64 + t * 16 + (lane & 15);
-                    fa[t] = __builtin_bit_cast(bf16x8, sA[swz(ar, ch)]);
-                    fw[t] = __builtin_bit_cast(bf16x8, sW[swz(wr, ch)]);
-                }
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#ifdef YMT3_PROBE_NO_MFMA
-                        acc[nt][mt][0] += (float)fw[nt][0] + (float)fa[mt][0];
-#else
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
-#endif
-            }
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[nt], fa0[mt], acc[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             --left;
             if (left > 0) {                                              // the next step's stage: landed (mine) and visible (barrier)
                 if (left > 1) WAIT_DMA_AND_BARRIER(6); else WAIT_DMA_AND_BARRIER(0);
             }
             st = st == NST - 1 ? 0 : st + 1;
+            if (left > 0) read_frags(st, 0, fa0, fw0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[nt], fa1[mt], acc[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #ifdef YMT3_PROBE_NO_STORE
         if (acc[0][0][0] != 12345.678f) continue;                        // timing-only build: keep the math, drop the stores
