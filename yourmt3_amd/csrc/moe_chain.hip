@@ -12,10 +12,12 @@
 // tiles of every stage at entry and hand 16-row tiles / expert pair sets to each other through arrival counters on 128-byte lines of their own and
 // agent-scope loads / stores (dec_chain.hip's protocol).  Workgroup (mt, nt) -- dec_chain's mapping -- owns:
 //     stage 0: row tile mt, 16-column tile nt < 32;  stage 1: rows 16 mt + 8 nt .. + 7 for nt < 2 (one wave per row);
-//     stages 2 and 3: expert e = mt + 4 (nt >> 5), tile j = nt & 31: hidden columns 64 j .. + 63, then output columns 16 j .. + 15;
+//     stage 2: expert e = mt + 4 (nt >> 5), tile j = nt & 31: hidden columns 64 j .. + 63 for all of e's pairs (up to 32 per MFMA pass);
+//     stage 3: the same expert; its 32 workgroups split the expert's PAIRS as well as the columns (fp8: 64 columns x a quarter of the pairs, bf16:
+//              32 columns x half of them), so the most popular expert costs one pass and a hidden row is read by 8 / 16 workgroups instead of 32;
 //     stage 4: row tile mt, 32-column tile nt of the next projection.
-// The arithmetic is that of the five kernels operation for operation (same K-slices per wave, MFMA chains, fixed-order reductions, chunks of
-// <= 16 pairs in ascending pair order, the fp8 form's per-row dynamic scale): ids are bit-identical to the launches (tests).
+// The arithmetic is that of the five kernels operation for operation (same K-slices per wave, MFMA chains, fixed-order reductions, the fp8 form's
+// per-row dynamic scale; a pair's outputs do not depend on which pairs share its pass or its workgroup): ids are bit-identical to the launches (tests).
 // Every wait is bounded (1 s) behind the handle's sticky abort word; the grid must be resident at once (runtime.hip asks the occupancy API).
 #include <cstdlib>
 
@@ -172,8 +174,9 @@ __device__ __forceinline__ void gather_rows(const MoeChainArgs& c, const int* pl
 
 // LDS map of the kernel (bytes from the start of the dynamic block)
 constexpr int L_PLIST = 0;                                 // the expert's pair list [128] + wcnt [8]
-constexpr int L_FP8 = 576;                                 // smax [32] (uint), sinv [32], sxs [32]: per-row fp8 scales of a pass of <= 32 pairs
-constexpr int L_WPART = L_FP8 + 96 * 4;                    // [8][16] floats (stage 4's sum(x^2) per wave)
+constexpr int MC_PASS_MAX = 64;                            // pairs a pass of the expert stages can take (an expert has at most R <= 64)
+constexpr int L_FP8 = 576;                                 // smax [64] (uint), sinv [64], sxs [64]: per-row fp8 scales of a pass
+constexpr int L_WPART = L_FP8 + 3 * MC_PASS_MAX * 4;                    // [8][16] floats (stage 4's sum(x^2) per wave)
 constexpr int L_RED = L_WPART + 8 * 16 * 4;                // cross-wave reduction: [8][16][64] floats in stage 2, [8][16][32] + 16 scales in stage 4, [8][16][16] elsewhere
 constexpr int L_STRIPS = L_RED + (8 * 16 * 64 + 16) * 4;   // operand strips of stages 0, 1 (router rows), 2 and 4
 constexpr int l_strips3(int nt) { return L_RED + (8 * 16 * 16 * nt + 16) * 4; }   // stage 3 (K = 2048, 16 nt columns): its 32-row strips start behind 8 nt KB of reduction space
@@ -188,7 +191,7 @@ constexpr int L_STRIPS_ALIGNED = L_STRIPS;
 // STAGE 0: hidden[p] = R(relu(xn[row(p)] . wi[e]^T)), 64 columns (NT = 4), K = 512, weights parked in LDS strips from `wreg` (row layout);
 // STAGE 1: y[p] = gate[p] * (hidden[p] . wo[e]^T), 16 NT columns, K = 2048, weights as MFMA fragments in registers: wreg[tt * KS + ks] (bf16, 16 B)
 //          or wreg8[tt * KS + ks] (fp8, 8 B).
-template <int STAGE, bool FP8, int NT>
+template <int STAGE, bool FP8, int NT, int NH>
 __device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* plist, int cnt_all, int col0, const u32x4* wreg, const long* wreg8, float wscale, char* smem) {
     constexpr int K = STAGE == 0 ? 512 : 2048;
     static_assert(STAGE == 1 || NT == 4, "stage 2 takes 64 hidden columns");
@@ -197,15 +200,16 @@ __device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* pl
     constexpr int LPR = KW * 2 / 16, RPI = 64 / LPR, NI = 16 / RPI;                               // a gathered bf16 row slice: lanes per row, rows per instruction
     constexpr int LPRW = FP8 ? KW / 16 : KW * 2 / 16, RPIW = 64 / LPRW, NIW = 16 * NT / RPIW;     // the weight rows of the tile as loaded (whole lines)
     constexpr bool WREG = STAGE == 1;
-    constexpr int NSTRIP = 2 + (WREG ? 0 : NT);
+    constexpr int NSTRIP = NH + (WREG ? 0 : NT);                                                  // per wave: NH activation strips of 16 rows, then the weight strips
+    constexpr int PASS = 16 * NH;                                                                 // pairs per pass
+    static_assert(PASS <= MC_PASS_MAX, "the per-row fp8 scales");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     float* red = reinterpret_cast<float*>(smem + L_RED);
     unsigned* smax = reinterpret_cast<unsigned*>(smem + L_FP8);
-    float* sinv = reinterpret_cast<float*>(smax + 32);
-    float* sxs = sinv + 32;
-    char* sA0 = smem + (STAGE == 0 ? L_STRIPS : l_strips3(NT)) + wave * NSTRIP * STRIP;
-    char* sA1 = sA0 + STRIP;
-    char* sW = sA1 + STRIP;
+    float* sinv = reinterpret_cast<float*>(smax + MC_PASS_MAX);
+    float* sxs = sinv + MC_PASS_MAX;
+    char* sA = smem + (STAGE == 0 ? L_STRIPS : l_strips3(NT)) + wave * NSTRIP * STRIP;          // half hh at sA + hh * STRIP
+    char* sW = sA + NH * STRIP;
     if constexpr (!WREG) {
 #pragma unroll
         for (int i = 0; i < NIW; ++i)
@@ -213,106 +217,119 @@ __device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* pl
     }
     const bool epi = tid < 16 * 8 * NT;
     const int mr = tid / (8 * NT), nq = (tid % (8 * NT)) * 2;
-    for (int c0 = 0; c0 < cnt_all; c0 += 32) {
-        const int cnt = min(32, cnt_all - c0);
-        const bool two = cnt > 16;                              // workgroup-uniform
-        u32x4 a0[NI], a1[NI];
-        gather_rows<STAGE>(c, plist, cnt_all, c0, a0);
-        if (two) gather_rows<STAGE>(c, plist, cnt_all, c0 + 16, a1);
-        float gt0 = 0.f, gt1 = 0.f;                             // STAGE 1: the pairs' gates, requested with the rows instead of behind the reduction
-        if constexpr (STAGE == 1) {
-            if (epi && mr < cnt) gt0 = ld_agent(c.gate + plist[c0 + mr]);
-            if (epi && 16 + mr < cnt) gt1 = ld_agent(c.gate + plist[c0 + 16 + mr]);
+    for (int c0 = 0; c0 < cnt_all; c0 += PASS) {
+        const int cnt = min(PASS, cnt_all - c0);
+        const int nh = (cnt + 15) >> 4;                         // halves in use: workgroup-uniform
+        u32x4 av[NH][NI];
+        float gt[NH];                                           // STAGE 1: the pairs' gates, requested with the rows instead of behind the reduction
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            gt[hh] = 0.f;
+            if (hh < nh) {
+                gather_rows<STAGE>(c, plist, cnt_all, c0 + 16 * hh, av[hh]);
+                if constexpr (STAGE == 1) {
+                    if (epi && 16 * hh + mr < cnt) gt[hh] = ld_agent(c.gate + plist[c0 + 16 * hh + mr]);
+                }
+            }
         }
         if constexpr (FP8) {
             // per-row dynamic scale (amax / 448): 8-lane DPP max, then one LDS integer max per (row, 8-lane group) -- |x| >= 0, so float bit patterns order like unsigned integers
-            if (tid < 32) smax[tid] = 0u;
+            if (tid < PASS) smax[tid] = 0u;
             __syncthreads();
-            auto row_max = [&](const u32x4 (&av)[NI], int base) {
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                if (hh >= nh) continue;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     float mx = 0.f;
 #pragma unroll
                     for (int jq = 0; jq < 4; ++jq) {
-                        mx = fmaxf(mx, fabsf(__uint_as_float(av[i][jq] << 16)));
-                        mx = fmaxf(mx, fabsf(__uint_as_float(av[i][jq] & 0xffff0000u)));
+                        mx = fmaxf(mx, fabsf(__uint_as_float(av[hh][i][jq] << 16)));
+                        mx = fmaxf(mx, fabsf(__uint_as_float(av[hh][i][jq] & 0xffff0000u)));
                     }
                     mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));
                     mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));
                     mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x141, 0xF, 0xF, true)));
-                    if ((lane & 7) == 0) atomicMax(&smax[base + i * RPI + lane / LPR], __float_as_uint(mx));
+                    if ((lane & 7) == 0) atomicMax(&smax[16 * hh + i * RPI + lane / LPR], __float_as_uint(mx));
                 }
-            };
-            row_max(a0, 0);
-            if (two) row_max(a1, 16);
+            }
             __syncthreads();
-            if (tid < 32) {
+            if (tid < PASS) {
                 const float mx = fmaxf(__uint_as_float(smax[tid]), 1e-12f);
                 sinv[tid] = 448.0f / mx;
                 sxs[tid] = mx / 448.0f;
             }
             __syncthreads();
-            auto quant = [&](const u32x4 (&av)[NI], int base, char* sA) {
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                if (hh >= nh) continue;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int row = i * RPI + lane / LPR;
-                    const float inv = sinv[base + row];
+                    const float inv = sinv[16 * hh + row];
+                    const u32x4 v = av[hh][i];
                     int lo = 0, hi = 0;
-                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][0] << 16) * inv, __uint_as_float(av[i][0] & 0xffff0000u) * inv, lo, false);
-                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][1] << 16) * inv, __uint_as_float(av[i][1] & 0xffff0000u) * inv, lo, true);
-                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][2] << 16) * inv, __uint_as_float(av[i][2] & 0xffff0000u) * inv, hi, false);
-                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(av[i][3] << 16) * inv, __uint_as_float(av[i][3] & 0xffff0000u) * inv, hi, true);
-                    *reinterpret_cast<int2*>(sA + row * PITCH + (lane % LPR) * 8) = make_int2(lo, hi);
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(v[0] << 16) * inv, __uint_as_float(v[0] & 0xffff0000u) * inv, lo, false);
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(v[1] << 16) * inv, __uint_as_float(v[1] & 0xffff0000u) * inv, lo, true);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(v[2] << 16) * inv, __uint_as_float(v[2] & 0xffff0000u) * inv, hi, false);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(v[3] << 16) * inv, __uint_as_float(v[3] & 0xffff0000u) * inv, hi, true);
+                    *reinterpret_cast<int2*>(sA + hh * STRIP + row * PITCH + (lane % LPR) * 8) = make_int2(lo, hi);
                 }
-            };
-            quant(a0, 0, sA0);
-            if (two) quant(a1, 16, sA1);
+            }
         } else {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int off = (i * RPI + lane / LPR) * PITCH + (lane % LPR) * 16;
-                *reinterpret_cast<u32x4*>(sA0 + off) = a0[i];
-                if (two) *reinterpret_cast<u32x4*>(sA1 + off) = a1[i];
+            for (int hh = 0; hh < NH; ++hh) {
+                if (hh >= nh) continue;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    *reinterpret_cast<u32x4*>(sA + hh * STRIP + (i * RPI + lane / LPR) * PITCH + (lane % LPR) * 16) = av[hh][i];
             }
         }
-        // MFMA: one chain per (half, 16-column tile) over this wave's K-slice; a weight fragment is read once for both halves
-        f32x4 acc0[NT], acc1[NT];
+        // MFMA: one chain per (half, 16-column tile) over this wave's K-slice; a weight fragment is read once for all halves
+        f32x4 acc[NH][NT];
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) { acc0[tt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[tt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) acc[hh][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if constexpr (FP8) {
                 const int o = li * PITCH + ks * 32 + g * 8;
-                const long af0 = *reinterpret_cast<const long*>(sA0 + o);
-                const long af1 = two ? *reinterpret_cast<const long*>(sA1 + o) : 0L;
+                long af[NH];
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) af[hh] = hh < nh ? *reinterpret_cast<const long*>(sA + hh * STRIP + o) : 0L;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     long wf;
                     if constexpr (WREG) wf = wreg8[tt * KS + ks];
                     else wf = *reinterpret_cast<const long*>(sW + tt * STRIP + o);
-                    acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf, af0, acc0[tt], 0, 0, 0);
-                    if (two) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf, af1, acc1[tt], 0, 0, 0);
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh)
+                        if (hh < nh) acc[hh][tt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf, af[hh], acc[hh][tt], 0, 0, 0);
                 }
             } else {
                 const int o = li * PITCH + (ks * 32 + g * 8) * 2;
-                const bf16x8 af0 = *reinterpret_cast<const bf16x8*>(sA0 + o);
-                bf16x8 af1 = af0;
-                if (two) af1 = *reinterpret_cast<const bf16x8*>(sA1 + o);
+                bf16x8 af[NH];
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) af[hh] = *reinterpret_cast<const bf16x8*>(sA + (hh < nh ? hh : 0) * STRIP + o);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     bf16x8 wf;
                     if constexpr (WREG) wf = __builtin_bit_cast(bf16x8, wreg[tt * KS + ks]);
                     else wf = *reinterpret_cast<const bf16x8*>(sW + tt * STRIP + o);
-                    acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af0, acc0[tt], 0, 0, 0);
-                    if (two) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af1, acc1[tt], 0, 0, 0);
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh)
+                        if (hh < nh) acc[hh][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[hh], acc[hh][tt], 0, 0, 0);
                 }
             }
         }
         // fixed-order cross-wave reduction and epilogue, one half after the other (the reduction space holds one)
-        for (int half = 0; half < (two ? 2 : 1); ++half) {
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            if (hh >= nh) continue;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                const f32x4 a = half ? acc1[tt] : acc0[tt];
+                const f32x4 a = acc[hh][tt];
                 *reinterpret_cast<float4*>(red + ((wave * 16 + li) * (16 * NT) + tt * 16 + g * 4)) = make_float4(a[0], a[1], a[2], a[3]);
             }
             __syncthreads();
@@ -323,7 +340,7 @@ __device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* pl
                     const float2 t = *reinterpret_cast<const float2*>(red + ((w * 16 + mr) * (16 * NT) + nq));
                     sv.x += t.x; sv.y += t.y;
                 }
-                const int rr = 16 * half + mr;
+                const int rr = 16 * hh + mr;
                 if (rr < cnt) {
                     const int pp = plist[c0 + rr];
                     if constexpr (FP8) {
@@ -333,8 +350,7 @@ __device__ __forceinline__ void expert_pass(const MoeChainArgs& c, const int* pl
                     if constexpr (STAGE == 0) {
                         st_agent(reinterpret_cast<uint32_t*>(c.hidden + (size_t)pp * 2048 + col0 + nq), pack_bf16x2(fmaxf(sv.x, 0.f), fmaxf(sv.y, 0.f)));
                     } else {
-                        const float gt = half ? gt1 : gt0;
-                        st2_agent(c.y + (size_t)pp * 512 + col0 + nq, make_float2(gt * sv.x, gt * sv.y));
+                        st2_agent(c.y + (size_t)pp * 512 + col0 + nq, make_float2(gt[hh] * sv.x, gt[hh] * sv.y));
                     }
                 }
             }
@@ -466,6 +482,7 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     __builtin_amdgcn_sched_barrier(0);
     // expert weights: stage 2 = hidden columns 64 ot .. + 63 of expert e2 (K = 512), row layout; stage 3 = output columns 16 NT3 ct .. of the same
     // expert (K = 2048) as MFMA fragments: lane (li, g) holds column li's k = 32 ks + 8 g .. + 7 of this wave's K-slice for every 16-column tile
+    constexpr int NH2 = 2;                                    // stage 2: 16-pair halves per pass (4 -- all of an expert's <= 64 pairs in one pass, fp8 form -- was measured: no faster, 334-336 vs 332.5 ms)
     constexpr int NT3 = FP8 ? 4 : 2;                          // stage 3: 16 NT3 columns per workgroup, the expert's pairs split NT3 ways (32 workgroups per expert either way)
     const int ct = ot % (32 / NT3), part = ot / (32 / NT3);   // ot = ct + (32 / NT3) part: the NT3 parts of a column tile sit on one XCD (blockIdx & 7 == nt & 7) and share its weights in L2
     constexpr int NW_IN = FP8 ? 4 : Geo<512, 4>::NIW;
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     const int cnt = find_pairs(c.sel, 2 * R, e2, plist, wcnt);
     float ws_in = 1.f, ws_out = 1.f;
     if constexpr (FP8) { ws_in = c.wi_s[e2]; ws_out = c.wo_s[e2]; }
-    if (cnt) expert_pass<0, FP8, 4>(c, plist, cnt, ot * 64, wi4, nullptr, ws_in, smem);
+    if (cnt) expert_pass<0, FP8, 4, NH2>(c, plist, cnt, ot * 64, wi4, nullptr, ws_in, smem);
     mc_signal(c.sync, MC_FFN_IN + e2 * 8);
     CH_MARK(c, 4);
     if constexpr (FP8) {
@@ -561,7 +578,7 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
         mc_wait(c.sync, MC_FFN_IN + e2 * 8, 32u, c.host_abort);
         CH_MARK(c, 5);
         const int per = (cnt + NT3 - 1) / NT3, first = min(cnt, part * per), mine = min(cnt, first + per) - first;
-        if (mine > 0) expert_pass<1, FP8, NT3>(c, plist + first, mine, ct * 16 * NT3, wo2, wo8, ws_out, smem);
+        if (mine > 0) expert_pass<1, FP8, NT3, 4 / NT3>(c, plist + first, mine, ct * 16 * NT3, wo2, wo8, ws_out, smem);     // a part has at most 64 / NT3 pairs: one pass
         mc_signal(c.sync, MC_FFN_OUT + e2 * 8);
         CH_MARK(c, 6);
     }
@@ -575,8 +592,9 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
 }
 
 constexpr size_t MOE_CHAIN_LDS_BF16 = (size_t)l_strips3(2) + (size_t)8 * 2 * 16 * (2048 / 8 * 2 + 16);               // stage 3: two 16-row activation strips per wave (weights in registers)
-constexpr size_t MOE_CHAIN_LDS_FP8 = (size_t)l_strips3(4) + (size_t)8 * 2 * 16 * (2048 / 8 + 16);
+constexpr size_t MOE_CHAIN_LDS_FP8 = (size_t)L_STRIPS + (size_t)8 * 32 * (256 + 16);                                // stage 3's weights on their way to fragments; stage 2: two activation + four weight strips per wave
 static_assert(MOE_CHAIN_LDS_BF16 >= (size_t)L_STRIPS + (size_t)8 * 6 * 16 * (512 / 8 * 2 + 16), "stage 2 (bf16): two activation + four weight strips per wave");
+static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)l_strips3(4) + (size_t)8 * 1 * 16 * (2048 / 8 + 16), "stage 3 (fp8): one activation strip per wave");
 static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS + (size_t)8 * 6 * 16 * (512 / 8 + 16), "stage 2 (fp8)");
 static_assert(MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS + (size_t)8 * 3 * 16 * (512 / 8 * 2 + 16), "stages 0 and 4 (bf16 strips) in the fp8 kernel");
 static_assert(MOE_CHAIN_LDS_BF16 >= (size_t)L_STRIPS + 8 * 512 * 4 && MOE_CHAIN_LDS_FP8 >= (size_t)L_STRIPS + 8 * 512 * 4, "router rows");
