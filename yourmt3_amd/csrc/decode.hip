@@ -591,17 +591,19 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
     const bf16_t* kb = pK + slab + sub * 8;
     const bf16_t* vb = pV + slab + sub * 8;
     const float* bias = SELF ? pF + (size_t)h * slab_keys : nullptr;      // the bias table's row pitch is the cache length (launcher checks)
-    if constexpr (OP && SELF) {
-        // this wave's 64 rows of wo (output columns 64w..64w+63), the head's 64 k each: 8 DMAs of 8 rows x 128 B.  LDS slot
-        // (row, pos) holds source chunk pos ^ (row & 7): the swizzle sits on the source address, the DMA writes linearly.
-        // (Requested at entry although hipcc's vmcnt(0) for q, in front of the key loop, then also waits for them: requested when the
-        // stream has been consumed instead, they land under the merge and lengthen the tail by more than the head gains --
-        // 259.5 against 253.9 ms per batch, profiles/r02_attn_pair_marks.txt.)
-        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wo_lds + (unsigned)wave * 8192u;
-        const bf16_t* src = a.wo + ((size_t)(wave * 64 + (lane >> 3)) * H + h) * DKV + ((lane & 7) ^ (lane >> 3)) * 8;
+    // OP && SELF: this wave's 64 rows of wo (output columns 64w..64w+63), the head's 64 k each: 8 DMAs of 8 rows x 128 B.  LDS slot
+    // (row, pos) holds source chunk pos ^ (row & 7): the swizzle sits on the source address, the DMA writes linearly.
+    // Issued BEHIND the wave's first K/V block (below): at entry, 512 workgroups' 64 KB pulls backed the vector-memory queues up and a
+    // wave's first K/V request left up to 5.9 us after entry (profiles/r02_attn_pair_marks.txt); requested when the stream has been consumed
+    // instead, they land under the merge and lengthen the tail by more than the head gains (259.5 against 253.9 ms per batch, same file).
+    auto issue_wo = [&]() {
+        if constexpr (OP && SELF) {
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wo_lds + (unsigned)wave * 8192u;
+            const bf16_t* src = a.wo + ((size_t)(wave * 64 + (lane >> 3)) * H + h) * DKV + ((lane & 7) ^ (lane >> 3)) * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) glds16(src + (size_t)i * 8 * H * DKV, lds0 + (unsigned)i * 1024u);
-    }
+            for (int i = 0; i < 8; ++i) glds16(src + (size_t)i * 8 * H * DKV, lds0 + (unsigned)i * 1024u);
+        }
+    };
 
     // q stays packed (4 x bf16x2); halves are widened to fp32 at use
     u32x4 qp;
@@ -713,7 +715,29 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
             load_block(ku, vu, ok, bv, kw, full_tag);
             compute_block(ku, vu, ok, bv, full_tag);
         };
-        for (int kw = wave * 8; kw < n_keys; kw += 8 * NW * U) {      // wave-uniform trip count: waves with no key skip everything
+        int kw = wave * 8;
+        if constexpr (OP && SELF) {
+            // the first block's K/V requests, then the wo DMAs, then its math (the inline-asm DMAs are invisible to hipcc's wait counts: its waits
+            // for the block's loads, which are older, do not wait for them until the block's last load is needed)
+            if (kw < n_keys) {
+                u32x4 ku[U], vu[U];
+                bool ok[U];
+                float bv[U];
+                if (n_keys - kw >= 8 * NW * U) {
+                    load_block(ku, vu, ok, bv, kw, std::true_type{});
+                    issue_wo();
+                    compute_block(ku, vu, ok, bv, std::true_type{});
+                } else {
+                    load_block(ku, vu, ok, bv, kw, std::false_type{});
+                    issue_wo();
+                    compute_block(ku, vu, ok, bv, std::false_type{});
+                }
+                kw += 8 * NW * U;
+            } else {
+                issue_wo();
+            }
+        }
+        for (; kw < n_keys; kw += 8 * NW * U) {      // wave-uniform trip count: waves with no key skip everything
             if (n_keys - kw >= 8 * NW * U) block(kw, std::true_type{});
             else block(kw, std::false_type{});
         }
