@@ -22,6 +22,8 @@ t0 = marks[:, 0].min()
 us = lambda v: (v - t0) / 100.0
 lab = ["entry", "self stream consumed", "partial stored", "row signalled", "row complete", "cross block consumed"]
 print(f"position {n - 1}; first-loads-issued stamp: min %.2f max %.2f; exit: min %.2f max %.2f" % (us(inout[:, 0]).min(), us(inout[:, 0]).max(), us(inout[:, 1]).min(), us(inout[:, 1]).max()))
+fl = np.sort(us(inout[:, 0]) - us(marks[:, 0]))
+print("first-loads-issued stamp - entry (the stamp waits for the scalar loads in front of it: kernarg words and the step counter): p10 %.2f median %.2f p90 %.2f max %.2f" % (fl[51], fl[256], fl[460], fl[-1]))
 for j, l in enumerate(lab):
     v = marks[:, j]
     print(f"{l:22s} min {us(v).min():6.2f} p10 {np.percentile(us(v), 10):6.2f} median {np.median(us(v)):6.2f} p90 {np.percentile(us(v), 90):6.2f} max {us(v).max():6.2f}")
