@@ -610,13 +610,16 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
     u32x4 wq_v[FUSEQ ? 8 : 1];
     float x_v = 0.f, g_v = 0.f, ss = 0.f;
     float pv[OP && FUSEQ ? 8 : 1];
-    if constexpr (FUSEQ) {
+    auto load_proj = [&]() {
         // operands of the fused projection: wave w owns outputs 8w..8w+7, lane l the k-chunk 8l..8l+7
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
             wq_v[jj] = *reinterpret_cast<const u32x4*>(pQ + ((size_t)h * DKV + wave * 8 + jj) * 512 + lane * 8);
         x_v = pF[(size_t)r * 512 + tid];
         g_v = pGain[tid];
+    };
+    if constexpr (FUSEQ) {
+        if constexpr (PAIR != 2) load_proj();
         if constexpr (OP) {
             if constexpr (PAIR != 2) {
 #pragma unroll
@@ -746,19 +749,24 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
         // order, so weight lines (L2 hits) queued behind another wave's K/V lines (HBM) reached the projection only after
         // most of the stream had arrived, and the projection ran exposed at the end (+2.7 us, profiles/r01_step_stamps.txt)
         if constexpr (PAIR == 2) {
-            // The projection's own operands are in flight (10 loads per lane: 8 wq, x, gain).  The self-attention half's partial
-            // stores are OLDER than these and vector-memory operations retire in issue order, so a wait that leaves 10 outstanding
-            // has seen them acknowledged: signal the row, wait for its eight heads, read their partials at agent scope.  The K/V
-            // block is requested AFTER this.  Requested before the hand-off, a poll (and the partials) came back behind it, in issue
+            // The self-attention half's partial stores are acknowledged (vmcnt(0)), the row is signalled, and only THEN are the projection's own
+            // operands requested (10 loads per lane: 8 wq, x, gain).  Round 2 issued them first and signalled behind `s_waitcnt vmcnt(10)` (the
+            // stores are older; vector-memory operations retire in issue order) so that the acknowledgement ran under the requests -- but a load
+            // instruction waits for room in the CU's vector-memory queue, which the other workgroups' K/V streams keep full, and that wait sat
+            // in front of the signal: 245.5 -> 241.6 ms per batch with the order turned round (same box, two builds interleaved,
+            // profiles/r03_notes.md).  The K/V block is requested after the hand-off.  Requested before it, a poll (and the partials) came
+            // back behind it, in issue
             // order, i.e. only once the whole block had arrived (254.5 ms per batch against 253.9); requested by the self-attention half
             // as soon as its own stream was consumed, it slowed the other workgroups' self-attention streams by more than it gained
             // (263 ms; profiles/r02_attn_pair_marks.txt).  (The pair kernel keeps hipcc from moving memory operations across the
             // boundary between the halves.)
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(ps.rows + (size_t)(2 * r) * CHAIN_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             PAIR_MARK(a, 3, wall_clock64());     // row signalled
+            load_proj();
+            __builtin_amdgcn_sched_barrier(0);
             pair_wait(ps, r);
             PAIR_MARK(a, 4, wall_clock64());     // the row's eight heads have arrived
 #pragma unroll
