@@ -329,7 +329,7 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
     const bool has0 = mt < n_mt && nt < 32, has1 = mt < n_mt, has3 = mt < n_mt && nt < n_nt3;
     const int nt0 = nt & 31, mt0 = mt, nt1 = nt, mt1 = mt, nt3 = nt < n_nt3 ? nt : nt - n_nt3, mt3 = mt;
 
-    // ---- stage 0 operands first (they are this kernel's critical path), then every later stage's weights
+    // ---- stage 0 operands first (they are this kernel's critical path), then stage 1's weights; stages 2 and 3 request theirs below
     u32x4 w0[G0::NIW], av[G0::NIA];
     load_w<512, 1>(pW0, nt0 * 16, w0);
     const int m0 = row0 + mt0 * 16;
@@ -384,10 +384,7 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
     __builtin_amdgcn_sched_barrier(0);
     u32x4 w1[G1::NIW], w2[W2F ? G2::KS : G2::NIW], w3[G1::NIW];
     load_w<512, 2>(pW1, nt1 * 32, w1);
-    if constexpr (W2F) load_w_frag<2048>(pW2, nt0 * 16, w2);
-    else load_w<2048, 1>(pW2, nt0 * 16, w2);
-    load_w<512, 2>(pW3, nt3 * 32, w3);
-    const f32x4 g1 = norm_gain(c.gain1), g3 = norm_gain(c.gain3);
+    const f32x4 g1 = norm_gain(c.gain1);
     __builtin_amdgcn_sched_barrier(0);
     CH_STAMP_IN(c);
 
@@ -415,6 +412,13 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
         chain_signal(c.sync, 0, mt0, nt0 & (nsub0 - 1));
         CH_MARK(c, 1);
     }
+    // The later stages' weights are requested as the stages come up, not all at entry as in round 2 (stage 2's here, stage 3's behind stage 1): a load
+    // instruction waits for room in the CU's vector-memory queue, and 112 KB of weight requests per workgroup at entry sat in front of the first
+    // stages' own loads and polls -- 240.0 -> 234.9 ms per batch, same box, two builds interleaved (profiles/r03_notes.md); each still has a stage's
+    // worth of time (2.5-4 us) to arrive
+    if constexpr (W2F) load_w_frag<2048>(pW2, nt0 * 16, w2);
+    else load_w<2048, 1>(pW2, nt0 * 16, w2);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- stage 1: FFN-in
     if (has1) {
         norm_park<2>(smem, w1);
@@ -425,6 +429,9 @@ __device__ __forceinline__ void chain_stages(const bf16_t* __restrict__ pW0, con
         chain_signal(c.sync, 1, mt1, nt1 & (nsub1 - 1));
         CH_MARK(c, 4);
     }
+    load_w<512, 2>(pW3, nt3 * 32, w3);
+    const f32x4 g3 = norm_gain(c.gain3);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- stage 2: FFN-out (the tile of stage 0 again: its h values are still in registers)
     if (has0) {
         float* red = reinterpret_cast<float*>(smem);

@@ -488,26 +488,32 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     constexpr int NW_IN = FP8 ? 4 : Geo<512, 4>::NIW;
     u32x4 wi4[NW_IN], wo2[FP8 ? 16 : NT3 * G2::KS], w3[G1::NIW];   // fp8: wo2 = the 64 rows' K-slices in row layout (whole lines; fragments are made of them below)
     long wo8[FP8 ? NT3 * G2::KS : 1];
+    // Requested as the stages come up, not all at entry (round 3, late: a load instruction waits for room in the CU's vector-memory queue, and
+    // 300 KB of weight requests per workgroup at entry sat in front of the first stages' own loads -- dec_chain_body.h, profiles/r03_notes.md):
+    // stage 2's tile now, stage 3's behind the router's stage, stage 4's behind stage 2
     if constexpr (FP8) {
         const uint8_t* Wi = static_cast<const uint8_t*>(pWi);
-        const uint8_t* Wo = static_cast<const uint8_t*>(pWo);
         // fp8 rows: K bytes; this wave's K-slice = KW bytes, 16 bytes per lane: 4 lanes per row of the K = 512 tile
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
             wi4[tt] = *reinterpret_cast<const u32x4*>(Wi + ((size_t)e2 * 2048 + ot * 64 + tt * 16 + lane / 4) * 512 + wave * 64 + (lane % 4) * 16);
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            wo2[i] = *reinterpret_cast<const u32x4*>(Wo + ((size_t)e2 * 512 + ct * 64 + i * 4 + lane / 16) * 2048 + wave * 256 + (lane % 16) * 16);
     } else {
         const bf16_t* Wi = static_cast<const bf16_t*>(pWi);
-        const bf16_t* Wo = static_cast<const bf16_t*>(pWo);
         load_w<512, 4>(Wi + (size_t)e2 * 2048 * 512, ot * 64, wi4);
-#pragma unroll
-        for (int tt = 0; tt < NT3; ++tt)
-            load_w_frag<2048>(Wo + (size_t)e2 * 512 * 2048, ct * 16 * NT3 + tt * 16, *reinterpret_cast<u32x4(*)[G2::KS]>(wo2 + tt * G2::KS));
     }
-    load_w<512, 2>(pW3, nt3 * 32, w3);
-    const f32x4 g3 = norm_gain(c.gain3);
+    auto load_wo = [&]() {
+        if constexpr (FP8) {
+            const uint8_t* Wo = static_cast<const uint8_t*>(pWo);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                wo2[i] = *reinterpret_cast<const u32x4*>(Wo + ((size_t)e2 * 512 + ct * 64 + i * 4 + lane / 16) * 2048 + wave * 256 + (lane % 16) * 16);
+        } else {
+            const bf16_t* Wo = static_cast<const bf16_t*>(pWo);
+#pragma unroll
+            for (int tt = 0; tt < NT3; ++tt)
+                load_w_frag<2048>(Wo + (size_t)e2 * 512 * 2048, ct * 16 * NT3 + tt * 16, *reinterpret_cast<u32x4(*)[G2::KS]>(wo2 + tt * G2::KS));
+        }
+    };
     __builtin_amdgcn_sched_barrier(0);
     CH_STAMP_IN(c);
 
@@ -547,6 +553,8 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     // ---- stage 2: expert FFN-in, 64 hidden columns of expert e2 for its pairs (an expert nobody chose costs a scan)
     int* plist = reinterpret_cast<int*>(smem + L_PLIST);
     int* wcnt = plist + 128;
+    load_wo();
+    __builtin_amdgcn_sched_barrier(0);
     mc_wait(c.sync, MC_ROUTER, (unsigned)(2 * n_mt), c.host_abort);
     CH_MARK(c, 3);
     const int cnt = find_pairs(c.sel, 2 * R, e2, plist, wcnt);
@@ -555,6 +563,9 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     if (cnt) expert_pass<0, FP8, 4, NH2>(c, plist, cnt, ot * 64, wi4, nullptr, ws_in, smem);
     mc_signal(c.sync, MC_FFN_IN + e2 * 8);
     CH_MARK(c, 4);
+    load_w<512, 2>(pW3, nt3 * 32, w3);
+    const f32x4 g3 = norm_gain(c.gain3);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (FP8) {
         // stage 3's weights from row layout to MFMA fragments through this wave's own strip space, 32 rows at a time (a wave's LDS accesses execute in
         // order: no barrier).  (Fragment-shaped 8-byte global loads at entry cost stage 0 ~2 us: 16 cache lines per instruction.)
