@@ -1,0 +1,20 @@
+#!/bin/bash
+# same-box A/B of two library builds on another BASELINE config: usage gpu_r03_lib_ab_cfg.sh <config index> <B> <L>
+set -o pipefail
+cat > /tmp/cfg_time.py <<'PY'
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+from yourmt3_amd.audio import synthetic_segments
+from yourmt3_amd.config import baseline_config
+from yourmt3_amd.model import YourMT3
+i, B, L = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+cfg = baseline_config(i)
+m = YourMT3(cfg, max_batch=B)
+a = torch.from_numpy(synthetic_segments(B, cfg.segment_samples)).cuda()
+m.inference(a, max_token_length=L); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(2): m.inference(a, max_token_length=L)
+torch.cuda.synchronize()
+print("configs[%d] B=%d L=%d: %.1f ms per batch, fallbacks %d" % (i, B, L, 1e3 * (time.perf_counter() - t0) / 2, m.merged_fallbacks))
+PY
+for i in 1 2 3; do for v in before after; do echo -n "$v: "; YMT3_LIB=$PWD/gpurun_ab/lib_$v.so timeout -k 10 300 python /tmp/cfg_time.py $1 $2 $3 2>&1 | grep -v amdgpu.ids || exit 1; done; done

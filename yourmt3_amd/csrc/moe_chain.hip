@@ -490,17 +490,19 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
     long wo8[FP8 ? NT3 * G2::KS : 1];
     // Requested as the stages come up, not all at entry (round 3, late: a load instruction waits for room in the CU's vector-memory queue, and
     // 300 KB of weight requests per workgroup at entry sat in front of the first stages' own loads -- dec_chain_body.h, profiles/r03_notes.md):
-    // stage 2's tile now, stage 3's behind the router's stage, stage 4's behind stage 2
-    if constexpr (FP8) {
-        const uint8_t* Wi = static_cast<const uint8_t*>(pWi);
-        // fp8 rows: K bytes; this wave's K-slice = KW bytes, 16 bytes per lane: 4 lanes per row of the K = 512 tile
+    // stage 2's tile behind stage 0, stage 3's behind the router's stage, stage 4's behind stage 2
+    auto load_wi = [&]() {
+        if constexpr (FP8) {
+            const uint8_t* Wi = static_cast<const uint8_t*>(pWi);
+            // fp8 rows: K bytes; this wave's K-slice = KW bytes, 16 bytes per lane: 4 lanes per row of the K = 512 tile
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-            wi4[tt] = *reinterpret_cast<const u32x4*>(Wi + ((size_t)e2 * 2048 + ot * 64 + tt * 16 + lane / 4) * 512 + wave * 64 + (lane % 4) * 16);
-    } else {
-        const bf16_t* Wi = static_cast<const bf16_t*>(pWi);
-        load_w<512, 4>(Wi + (size_t)e2 * 2048 * 512, ot * 64, wi4);
-    }
+            for (int tt = 0; tt < 4; ++tt)
+                wi4[tt] = *reinterpret_cast<const u32x4*>(Wi + ((size_t)e2 * 2048 + ot * 64 + tt * 16 + lane / 4) * 512 + wave * 64 + (lane % 4) * 16);
+        } else {
+            const bf16_t* Wi = static_cast<const bf16_t*>(pWi);
+            load_w<512, 4>(Wi + (size_t)e2 * 2048 * 512, ot * 64, wi4);
+        }
+    };
     auto load_wo = [&]() {
         if constexpr (FP8) {
             const uint8_t* Wo = static_cast<const uint8_t*>(pWo);
@@ -540,6 +542,8 @@ __global__ __launch_bounds__(512) void moe_chain_kernel(const bf16_t* __restrict
         mc_signal(c.sync, MC_B0 + mt * 8);
         CH_MARK(c, 0);
     }
+    load_wi();
+    __builtin_amdgcn_sched_barrier(0);
     // ---- stage 1: router, one wave per row: workgroups (mt, nt = 0 / 1) take rows 16 mt + 8 nt .. + 7
     if (has0 && nt0 < 2) {
         mc_wait(c.sync, MC_B0 + mt * 8, 32u, c.host_abort);
