@@ -1,0 +1,5 @@
+#!/bin/bash
+set -o pipefail
+for i in 1 2 3; do for v in 0 1; do
+  echo -n "W2F=$v: "; YMT3_CHAIN_W2F=$v timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step %.2f' % d['ms_per_step'], d['decode_step_breakdown_us'])" || exit 1
+done; done
