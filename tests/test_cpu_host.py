@@ -235,11 +235,19 @@ print("rank", rank, "ok")
 """
 
 
+def _free_port():
+    """A port nobody is listening on right now (fixed ports collided with earlier runs' sockets in TIME_WAIT once in a while)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 @pytest.mark.parametrize("n", [8, 7])
 def test_all_gather_world_size_2_gloo(tmp_path, n):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + n), WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
@@ -252,7 +260,7 @@ def test_all_gather_world_size_8_gloo_ragged(tmp_path, n):
     ranks own nothing and contribute padding only), ids back in segment order on every rank, per-rank stats gathered."""
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + n), WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="8", OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
