@@ -250,7 +250,7 @@ def test_all_gather_world_size_2_gloo(tmp_path, n):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=180)[0] for p in procs]
+    outs = [p.communicate(timeout=900)[0] for p in procs]       # (a cold `import torch` in every rank can take minutes on a freshly built tree)
     assert all(p.returncode == 0 for p in procs), outs
 
 
@@ -263,7 +263,7 @@ def test_all_gather_world_size_8_gloo_ragged(tmp_path, n):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="8", OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
+    outs = [p.communicate(timeout=1500)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
 
 
@@ -275,8 +275,8 @@ def test_launcher_starts_one_rank_per_gpu_and_gathers(tmp_path):
     script.write_text(_WORKER)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     code = ("import sys; sys.path.insert(0, %r); from yourmt3_amd.dist import launch_local_ranks; "
-            "sys.exit(launch_local_ranks(2, [sys.executable, %r, %r, '7'], timeout=170))" % (ROOT, str(script), ROOT))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=200)
+            "sys.exit(launch_local_ranks(2, [sys.executable, %r, %r, '7'], timeout=850))" % (ROOT, str(script), ROOT))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert sorted(l for l in r.stdout.splitlines() if l.startswith("rank")) == ["rank 0 ok", "rank 1 ok"]
     # a failing rank ends the job with its exit code instead of leaving the others in a collective
@@ -291,13 +291,13 @@ def test_bench_refuses_a_rank_count_mismatch_and_never_runs_without_a_gpu():
     """No silent 1-rank run when N ranks were asked for; and with no GPU the ranks fail loudly (no CPU fallback)."""
     bench = os.path.join(ROOT, "bench.py")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
     import torch
     if not torch.cuda.is_available():
         env.pop("WORLD_SIZE", None)
         r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                           env=dict(env, YMT3_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+                           env=dict(env, YMT3_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
         assert r.returncode != 0 and "GPU" in (r.stdout + r.stderr) and '"metric"' not in r.stdout
 
 
