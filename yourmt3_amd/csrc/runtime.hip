@@ -1045,6 +1045,35 @@ static int decode_run(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int3
             // fork: every chain stream waits for the cross-KV GEMM + init on the caller's stream
             HIP_TRY(hipEventRecord(h->fork_ev, s));
             for (int c = 0; c < n_chains; ++c) HIP_TRY(hipStreamWaitEvent(h->chain_stream[c], h->fork_ev, 0));
+            // as for one chain: graph_steps consecutive steps of a chain are ONE replayed graph (the boundary between two graph launches costs ~7 us
+            // of stream time that a kernel boundary inside a graph does not)
+            const int G = h->graph_steps;
+            hipGraphExec_t mexec[8] = {};
+            if (G > 1 && n_steps >= G) {
+                for (int c = 0; c < n_chains; ++c) {
+                    StepGraph& mg = h->step_graphs[((((long)B * 16 + n_chains) * 16 + c)) | (1L << 40) | ((long)G << 32)];
+                    if (!mg.exec) {
+                        HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+                        int rc = 0;
+                        for (int i = 0; i < G && !rc; ++i) rc = launch_step(h, B, row0[c], row0[c + 1] - row0[c], h->shared + c, h->cap_stream, false);
+                        hipError_t e = hipStreamEndCapture(h->cap_stream, &mg.graph);
+                        if (rc) return rc;
+                        if (e != hipSuccess) FAIL(YMT3_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+                        HIP_TRY(hipGraphInstantiate(&mg.exec, mg.graph, nullptr, nullptr, 0));
+                        mg.merged = h->step_merged;
+                    }
+                    mexec[c] = mg.exec;
+                }
+            }
+            auto feed = [&](int c) -> bool {
+                int t = 0;
+                if (mexec[c])
+                    for (; t + G <= n_steps; t += G)
+                        if (hipGraphLaunch(mexec[c], h->chain_stream[c]) != hipSuccess) return false;
+                for (; t < n_steps; ++t)
+                    if (hipGraphLaunch(exec[c], h->chain_stream[c]) != hipSuccess) return false;
+                return true;
+            };
             if (h->chain_threads) {
                 // one host thread per chain: a hipGraphLaunch of the ~44-node step costs the host 60-150 us, so ONE thread
                 // feeding n chains is host-bound as soon as a chain's step is shorter than n launches
@@ -1053,14 +1082,13 @@ static int decode_run(ymt3_handle h, const bf16_t* enc, int B, int n_steps, int3
                 for (int c = 1; c < n_chains; ++c)
                     th.emplace_back([&, c] {
                         if (hipSetDevice(h->device) != hipSuccess) { bad = 1; return; }
-                        for (int t = 0; t < n_steps && !bad; ++t)
-                            if (hipGraphLaunch(exec[c], h->chain_stream[c]) != hipSuccess) bad = 1;
+                        if (!feed(c)) bad = 1;
                     });
-                for (int t = 0; t < n_steps && !bad; ++t)
-                    if (hipGraphLaunch(exec[0], h->chain_stream[0]) != hipSuccess) bad = 1;
+                if (!feed(0)) bad = 1;
                 for (auto& t : th) t.join();
                 if (bad) FAIL(YMT3_ERR_HIP, "hipGraphLaunch failed on a decode chain: %s", hipGetErrorString(hipGetLastError()));
             } else {
+                // (the caller's thread feeds all chains: step by step, so that no chain runs ahead of the others' launches)
                 for (int t = 0; t < n_steps; ++t)
                     for (int c = 0; c < n_chains; ++c) HIP_TRY(hipGraphLaunch(exec[c], h->chain_stream[c]));
             }
