@@ -530,13 +530,15 @@ struct PairSync {
     unsigned* abort_word;       // the handle's sticky abort word (shared with the GEMM chain)
     unsigned* host_abort;
 };
-__device__ __forceinline__ void pair_wait(const PairSync& ps, int r) {
+// Returns (thread 0) the number of heads that had left the row before this one, or ~0u after an abort: the departure count is REQUESTED here, behind
+// the barrier, and looked at only at the end of the kernel (pair_leave) -- as a fetch-add whose result thread 0 waited for in front of the barrier it
+// put a memory round trip (~0.7 us) on every workgroup's way out of the hand-off.
+__device__ __forceinline__ unsigned pair_wait(const PairSync& ps, int r) {
+    bool ok = true;
     if (threadIdx.x == 0) {
         unsigned* arr = ps.rows + (size_t)(2 * r) * CHAIN_LINE;
-        unsigned* dep = arr + CHAIN_LINE;
         unsigned long long t0 = 0;
         unsigned polls = 0;
-        bool ok = true;
         while (__hip_atomic_load(arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u) {
             if ((++polls & 63u) == 0u) {
                 const unsigned long long now = wall_clock64();
@@ -549,13 +551,19 @@ __device__ __forceinline__ void pair_wait(const PairSync& ps, int r) {
                 }
             }
         }
-        // the last of the row's eight heads to get here leaves both counters at zero for the next launch
-        if (ok && __hip_atomic_fetch_add(dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7u) {
-            __hip_atomic_store(arr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dep, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
     __syncthreads();
+    unsigned before = ~0u;
+    if (threadIdx.x == 0 && ok) before = __hip_atomic_fetch_add(ps.rows + (size_t)(2 * r + 1) * CHAIN_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return before;
+}
+// the last of the row's eight heads to have left leaves both counters at zero for the next launch
+__device__ __forceinline__ void pair_leave(const PairSync& ps, int r, unsigned before) {
+    if (threadIdx.x == 0 && before == 7u) {
+        unsigned* arr = ps.rows + (size_t)(2 * r) * CHAIN_LINE;
+        __hip_atomic_store(arr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(arr + CHAIN_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <bool SELF, bool FUSEQ, int NW, bool OP, int PAIR>
@@ -610,6 +618,7 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
     u32x4 wq_v[FUSEQ ? 8 : 1];
     float x_v = 0.f, g_v = 0.f, ss = 0.f;
     float pv[OP && FUSEQ ? 8 : 1];
+    unsigned left_before = ~0u;                 // PAIR == 2: pair_wait's departure count (thread 0)
     auto load_proj = [&]() {
         // operands of the fused projection: wave w owns outputs 8w..8w+7, lane l the k-chunk 8l..8l+7
 #pragma unroll
@@ -767,7 +776,7 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
             PAIR_MARK(a, 3, wall_clock64());     // row signalled
             load_proj();
             __builtin_amdgcn_sched_barrier(0);
-            pair_wait(ps, r);
+            left_before = pair_wait(ps, r);
             PAIR_MARK(a, 4, wall_clock64());     // the row's eight heads have arrived
 #pragma unroll
             for (int w = 0; w < 8; ++w) pv[w] = __hip_atomic_load(pPart + ((size_t)r * H + w) * 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -926,6 +935,7 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ pK, const b
         if (a.chain_sync && blockIdx.x == 0 && tid < CHAIN_COUNTERS) a.chain_sync[tid * CHAIN_LINE] = 0u;      // the next launch's arrival counters (dec_chain.hip)
     }
     if constexpr (PAIR == 1) PAIR_MARK(a, 2, wall_clock64());     // O-projection partial stored
+    if constexpr (PAIR == 2) pair_leave(ps, r, left_before);
     if constexpr (PAIR != 1) STAMP_OUT(a);
 }
 
