@@ -824,6 +824,11 @@ def test_automatic_two_chains_at_many_rows_give_the_single_chain_ids():
     assert torch.equal(t_auto, t_one)
     assert m_auto.last_decode_chains == 2 and m_one.last_decode_chains == 1
     assert len({tuple(r.flatten().tolist()) for r in t_one}) > 8                  # (the rows are not copies of each other)
+    # teacher forcing with logits returned goes through the same two chains: same logits, bit for bit
+    f_one, l_one = m_one.decode(e, 24, forced=t_one[..., :24].contiguous().cuda(), return_logits=True)
+    f_auto, l_auto = m_auto.decode(e, 24, forced=t_one[..., :24].contiguous().cuda(), return_logits=True)
+    assert m_auto.last_decode_chains == 2
+    assert torch.equal(f_auto.cpu(), f_one.cpu()) and torch.equal(l_auto.cpu(), l_one.cpu())
     m_one.close(); m_auto.close()
 
 
